@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures from the REFERENCE's own classes (run in the build container only).
+
+    python -B tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Imports ``/root/reference/SRFR_model.py`` (torch + numpy only), applies the trainer's
+xavier_normal_ init (reference trainer.py:364-369) under a fixed seed, and records, per class:
+inputs, the full state_dict, eval-mode ``forward`` outputs, ``predict`` logits, and - with
+``dropout_rate=0`` - the restated train step of reference trainer.py:31-41: loss, every parameter
+gradient, and weights after 1 and 3 ``torch.optim.Adam(lr=1e-3, betas=(0.9, 0.98))`` steps.
+Only inputs/outputs are stored; no reference source text is copied.  The reference does not exist
+on the GPU box, so nothing at test time imports it.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+import SRFR_model as ref  # noqa: E402
+
+I, L, B = 120, 20, 8
+D_ITEM, D_FAKE, NB, NH = 45, 5, 2, 1
+
+
+def make_inputs(seed, I=I, L=L, B=B):
+    g = np.random.RandomState(seed)
+    seq = np.zeros((B, L), np.int64)
+    rsq = np.zeros((B, L), np.int64)
+    pos = np.zeros((B, L), np.int64)
+    prs = np.zeros((B, L), np.int64)
+    neg = np.zeros((B, L), np.int64)
+    nrs = np.zeros((B, L), np.int64)
+    lens = g.randint(2, L + 1, size=B)
+    lens[0] = L            # one full sequence
+    lens[1] = 1            # one very short sequence
+    for b in range(B):
+        n = int(lens[b])
+        items = g.randint(1, I + 1, size=n + 1)
+        revs = g.choice([1, 2], size=n + 1, p=[0.3, 0.7])
+        if b == 2:          # fake/real tie (even count) for the label rounding edge
+            n2 = (n // 2) * 2
+            revs[:n2] = np.tile([1, 2], n2 // 2)
+        if b == 3:
+            revs[:] = 1     # all fake
+        seq[b, L - n:] = items[:n]
+        rsq[b, L - n:] = revs[:n]
+        pos[b, L - n:] = items[1:n + 1]
+        prs[b, L - n:] = revs[1:n + 1]
+        neg[b, L - n:] = g.randint(1, I + 1, size=n)
+        nrs[b, L - n:] = 1
+    return seq, rsq, pos, prs, neg, nrs
+
+
+def build(kind, dropout):
+    if kind == "SASRec":
+        return ref.SASRec(I, L, D_ITEM + D_FAKE, dropout, NB, NH, "cpu")
+    if kind == "SRFR":
+        return ref.SRFR(I, L, D_ITEM, D_FAKE, dropout, NB, NH, "cpu")
+    if kind == "SRFRN":
+        return ref.SRFRN(I, L, D_ITEM, D_FAKE, dropout, NB, NH, "cpu")
+    nl = {"SRFU_B": 3, "SRFU_F": L + 1, "SRFU_R": 11}[kind]
+    return getattr(ref, kind)(I, L, D_ITEM + D_FAKE, nl, dropout, NB, NH, "cpu")
+
+
+def trainer_init(model):
+    for _, p in model.named_parameters():          # reference trainer.py:364-369
+        try:
+            torch.nn.init.xavier_normal_(p.data)
+        except Exception:
+            pass
+    # 1-D params keep defaults (zeros/ones): perturb them too so that bias/LN paths are pinned
+    # (a fixture-only choice; still the reference's forward on these weights)
+    g = torch.Generator().manual_seed(99)
+    for _, p in model.named_parameters():
+        if p.dim() == 1:
+            p.data.add_(0.05 * torch.randn(p.shape, generator=g))
+
+
+def t64(a):
+    return torch.from_numpy(a)
+
+
+def main():
+    torch.set_num_threads(1)
+    for k_i, kind in enumerate(["SASRec", "SRFR", "SRFRN", "SRFU_B", "SRFU_F", "SRFU_R"]):
+        torch.manual_seed(1234 + k_i)
+        model = build(kind, 0.0)
+        trainer_init(model)
+        seq, rsq, pos, prs, neg, nrs = make_inputs(7 + k_i)
+        out = {"seq": seq, "rsq": rsq, "pos": pos, "prs": prs, "neg": neg, "nrs": nrs}
+        sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        for k, v in sd0.items():
+            out["w/" + k] = v.numpy()
+        model.eval()
+        u = torch.zeros(B, dtype=torch.int64)
+        h, pl, nl = model(u, t64(seq), t64(rsq), t64(pos), t64(prs), t64(neg), t64(nrs))
+        out["hidden"], out["pos_logits"], out["neg_logits"] = h.detach().numpy(), pl.detach().numpy(), nl.detach().numpy()
+        # predict: one user at a time over 101 candidates (reference utils.py:576-589)
+        g = np.random.RandomState(5)
+        cands = g.randint(1, I + 1, size=(B, 101)).astype(np.int64)
+        pred = np.stack([model.predict(u[b:b + 1], t64(seq[b:b + 1]), t64(rsq[b:b + 1]), t64(cands[b])).detach().numpy()
+                         for b in range(B)])
+        out["cands"], out["pred_logits"] = cands, pred
+        if kind.startswith("SRFU"):
+            out["labels"] = model.get_Labels(t64(rsq)).numpy().astype(np.int64)
+        # train step restated from reference trainer.py:31-41 (model.train(), dropout_rate = 0)
+        model.train()
+        crit = torch.nn.BCEWithLogitsLoss()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))
+        for step in range(3):
+            h, pl, nl = model(user_ids=u, input_ids=t64(seq), fake_ids=t64(rsq), positive_ids=t64(pos),
+                              positive_fake_ids=t64(prs), negative_ids=t64(neg), negative_fake_ids=t64(nrs))
+            opt.zero_grad()
+            idx = torch.where(t64(pos) != 0)
+            loss = crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
+            for p in model.parameters():
+                loss = loss + 0.0 * torch.norm(p)
+            loss.backward()
+            if step == 0:
+                out["loss0"] = np.float32(loss.item())
+                for k, p in model.named_parameters():
+                    out["g/" + k] = p.grad.detach().numpy().copy()
+            opt.step()
+            if step in (0, 2):
+                for k, v in model.state_dict().items():
+                    out[f"w{step + 1}/" + k] = v.detach().numpy().copy()
+            out[f"loss{step}"] = np.float32(loss.item())
+        path = os.path.join(HERE, f"{kind}.npz")
+        np.savez_compressed(path, **out)
+        print(kind, "->", path, os.path.getsize(path) // 1024, "KiB")
+
+    # get_Labels edge-case matrix (integer, bit-exact): ties, all-pad, all-fake, all-real
+    edge = np.array([[0] * 10, [1] * 10, [2] * 10, [1, 2] * 5, [0, 0, 0, 0, 1, 1, 1, 2, 2, 2],
+                     [0, 0, 0, 0, 0, 0, 0, 0, 0, 1], [0, 0, 0, 0, 0, 0, 0, 0, 0, 2], [0, 0, 1, 2, 2, 2, 2, 2, 2, 2],
+                     [1, 1, 1, 1, 1, 1, 1, 2, 2, 2], [0, 1, 1, 1, 1, 1, 1, 1, 1, 2]], np.int64)
+    lab = {"fake_ids": edge}
+    for kind, nl in (("SRFU_B", 3), ("SRFU_F", 11), ("SRFU_R", 11)):
+        m = getattr(ref, kind)(I, 10, 50, nl, 0.0, 1, 1, "cpu")
+        rows = edge if kind != "SRFU_R" else edge[1:]     # all-pad row is 0/0 -> NaN -> INT_MIN in the reference
+        lab[kind] = m.get_Labels(t64(rows)).numpy().astype(np.int64)
+    m = ref.SRFRN(I, 10, 45, 5, 0.0, 1, 1, "cpu")
+    fi = t64(edge)
+    lab["SRFRN_predict"] = (torch.sign(torch.count_nonzero(fi == 1, dim=1) - torch.count_nonzero(fi == 2, dim=1))
+                            * 0.5 + 1.5).int().numpy().astype(np.int64)
+    np.savez_compressed(os.path.join(HERE, "labels_edge.npz"), **lab)
+    print("labels_edge done")
+
+
+if __name__ == "__main__":
+    main()
