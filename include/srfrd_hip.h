@@ -1,0 +1,194 @@
+/*
+ * srfrd_hip.h  --  C ABI of libsrfrd_hip.so, the MI355X (gfx950) implementation of the SRFRD hot path.
+ *
+ * The reference (oss0430/SRFRD) has no FFI: its hot path is the Python nn.Module API
+ * `model(user_ids, input_ids, fake_ids, positive_ids, positive_fake_ids, negative_ids, negative_fake_ids)`
+ * (reference SRFR_model.py:92, :192, :473, :651), `model.predict(...)` (:144, :241, :532, :668) and the
+ * train step of reference trainer.py:27-41.  Every device operation those calls perform in stock torch
+ * ops is replaced by the launchers below; `srfrd_amd/` (Python) keeps the reference's module / state_dict
+ * surface on top of them (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
+ *  - the caller owns every buffer; launchers only enqueue work on `stream` (hipStream_t passed as void*),
+ *    never allocate, synchronise or touch global mutable state => graph-capturable and re-entrant;
+ *  - return value: 0 = ok, < 0 = argument / capability error (SRFRD_E_*), > 0 = hipError_t of the launch;
+ *  - ids are int64 (torch LongTensor, reference trainer.py:29), row-major (B, L), left-padded with 0;
+ *  - all floating-point data is fp32 (dtype "f32"); integer label / rank work is exact.
+ */
+#ifndef SRFRD_HIP_H
+#define SRFRD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRFRD_MAX_BLOCKS 8
+#define SRFRD_MAX_D 64          /* hidden width limit of the fused kernels (one lane per channel) */
+
+enum srfrd_kind {               /* reference classes, SRFR_model.py */
+  SRFRD_SASREC = 0,             /* :572 */
+  SRFRD_SRFR = 1,               /* :53  */
+  SRFRD_SRFRN = 2,              /* :154 */
+  SRFRD_SRFU_B = 3,             /* :543 */
+  SRFRD_SRFU_F = 4,             /* :553 */
+  SRFRD_SRFU_R = 5              /* :562 */
+};
+
+enum srfrd_error {
+  SRFRD_E_ARG = -1,             /* bad argument (null pointer, size out of range) */
+  SRFRD_E_UNSUPPORTED = -2,     /* configuration outside what the fused kernels cover (D > 64, heads != 1, L too long for LDS) */
+  SRFRD_E_DEVICE = -3           /* not a gfx950 device / LDS attribute could not be set */
+};
+
+/* Per-block element offsets into the dense parameter vector (SURVEY Appendix B names in comments). */
+typedef struct srfrd_block_off {
+  int64_t ln1_w, ln1_b;         /* attention_layernorms.i.{weight,bias}          (D)      */
+  int64_t in_w, in_b;           /* attention_layers.i.in_proj_{weight,bias}      (3D,D),(3D) */
+  int64_t out_w, out_b;         /* attention_layers.i.out_proj.{weight,bias}     (D,D),(D) */
+  int64_t ln2_w, ln2_b;         /* forward_layernorms.i.{weight,bias}            (D)      */
+  int64_t c1_w, c1_b;           /* forward_layers.i.conv1.{weight,bias}          (D,D,1),(D) */
+  int64_t c2_w, c2_b;           /* forward_layers.i.conv2.{weight,bias}          (D,D,1),(D) */
+} srfrd_block_off;
+
+/*
+ * Model geometry + the canonical layout of the "dense" parameter vector: every parameter except the item
+ * table, concatenated in this order.  The same offsets index the parameters, a dense-gradient slab and the
+ * Adam moments, so one descriptor serves forward, backward, reduce and optimizer.
+ */
+typedef struct srfrd_layout {
+  int32_t kind, n_items, max_len, d_item, d_fake, D, d_out, n_labels, n_blocks, n_heads;
+  int32_t side_rows, side_cols; /* fake_embed (3,d_fake) | user_label_embed (n_labels,D) | none (0,0) */
+  int64_t off_pos;              /* pos_embed / pos_emb                  (max_len, d_item) */
+  int64_t off_side;             /* fake_embed / user_label_embed        (side_rows, side_cols) */
+  srfrd_block_off blk[SRFRD_MAX_BLOCKS];
+  int64_t off_lc_w, off_lc_b;   /* last_conv.{weight,bias}  (d_item,D,1),(d_item)   SRFR only, else -1 */
+  int64_t off_ll_w, off_ll_b;   /* last_layernorm.{weight,bias}         (d_out) */
+  int64_t n_dense;              /* elements in the dense vector */
+  int64_t n_table;              /* (n_items + 1) * d_item */
+} srfrd_layout;
+
+/* [host] fills `lay`; replaces the per-class constructors' shape logic (reference SRFR_model.py:54-90, 155-190,
+ * 431-466, 573-615). */
+int srfrd_layout_init(srfrd_layout* lay, int kind, int n_items, int max_len, int d_item, int d_fake,
+                      int n_labels, int n_blocks, int n_heads);
+
+/* [host] capability query: dynamic LDS bytes the fused forward / backward kernels need for sequence length L
+ * (0 if L does not fit the 160 KiB LDS of a gfx950 CU). */
+int srfrd_lds_bytes(const srfrd_layout* lay, int L, int64_t* fwd_bytes, int64_t* bwd_bytes);
+
+/* [host] number of persistent workgroups the backward launches for batch B (= rows of `grad_slabs`). */
+int srfrd_bwd_grid(int B);
+
+/* [host] floats per debug-tap slot and number of slots (tests only). */
+int srfrd_debug_shape(const srfrd_layout* lay, int L, int64_t* slot_floats, int32_t* n_slots);
+
+/*
+ * Fused forward: embedding gather (+pos, +fake / user-label channel, pad mask), n_blocks x
+ * {LN -> causal self-attention -> +res -> LN -> PW-FFN -> mask}, (last_conv), last LN, pos/neg logits and the
+ * masked-BCE partial sums.  Replaces reference SRFR_model.py:92-142 (and the SRFRN / SRFU / SASRec twins)
+ * plus the loss terms of reference trainer.py:36-38.
+ *
+ *  item_table (n_items+1, d_item), dense (n_dense)           parameters
+ *  input_ids, fake_ids (B,L); fake_ids may be NULL (SASRec ignores it; SRFR/SRFRN treat NULL as all-zero,
+ *    reference SRFR_model.py:27-28)
+ *  pos_ids/neg_ids (B,L) or NULL (no logits, reference :126-136); pos_fake/neg_fake used by SRFRN only
+ *  dropout_p > 0 selects train mode; masks come from the counter hash of srfrd_rng.h keyed by
+ *    (seed, site, seq_index0 + b, row, col); if seed_dev != NULL the seed is read from device memory
+ *  hidden (B,L,d_out), pos_logits/neg_logits (B,L) outputs (logit pointers may be NULL iff the id pointer is)
+ *  save_x (n_blocks+1, B, L, D): block inputs and the last block's output; save_h1 (n_blocks, B, L, D):
+ *    post-attention residual; both NULL for inference
+ *  loss_part (B,3) or NULL: per sequence {sum softplus(-pos), sum softplus(neg), count} over pos_ids != 0
+ *  dbg / dbg_seq: debug taps of one sequence (tests only; NULL otherwise)
+ */
+int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const float* dense,
+                      const int64_t* input_ids, const int64_t* fake_ids,
+                      const int64_t* pos_ids, const int64_t* pos_fake,
+                      const int64_t* neg_ids, const int64_t* neg_fake,
+                      int B, int L, double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
+                      float* hidden, float* pos_logits, float* neg_logits,
+                      float* save_x, float* save_h1, float* loss_part,
+                      float* dbg, int dbg_seq, void* stream);
+
+/*
+ * Fused backward of the above (recomputes block internals in LDS from save_x / save_h1).  Replaces the
+ * autograd pass behind `loss.backward()` (reference trainer.py:40).
+ *
+ *  fused_bce != 0: d(pos_logits) = (sigmoid(pos)-1)[pos_ids!=0], d(neg_logits) = sigmoid(neg)[pos_ids!=0]
+ *    (SUM reduction: the 1/count of the two means is applied by srfrd_adam_step via `stats`), d_hidden = 0;
+ *  fused_bce == 0: upstream gradients d_hidden (B,L,d_out) / d_pos / d_neg (B,L) are read (each may be NULL).
+ *  grad_table (n_items+1, d_item): += by float atomics (caller zeroes it; row 0 never written: padding_idx)
+ *  grad_slabs (srfrd_bwd_grid(B), n_dense): per-workgroup partial dense gradients (fully overwritten)
+ */
+int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const float* dense,
+                      const int64_t* input_ids, const int64_t* fake_ids,
+                      const int64_t* pos_ids, const int64_t* pos_fake,
+                      const int64_t* neg_ids, const int64_t* neg_fake,
+                      int B, int L, double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
+                      const float* hidden, const float* pos_logits, const float* neg_logits,
+                      const float* save_x, const float* save_h1,
+                      const float* d_hidden, const float* d_pos, const float* d_neg, int fused_bce,
+                      float* grad_table, float* grad_slabs,
+                      float* dbg, int dbg_seq, void* stream);
+
+/* Sums the per-workgroup slabs into grad_dense (n_dense) in a fixed order (bitwise reproducible) and, if
+ * loss_part != NULL, reduces it into stats[0..3] = {sum softplus(-pos), sum softplus(neg), count, 0}. */
+int srfrd_reduce_dense(const float* grad_slabs, int n_slabs, int64_t n_dense, float* grad_dense,
+                       const float* loss_part, int B, float* stats, void* stream);
+
+/*
+ * Optimizer state advance (one thread): t += 1, step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t)
+ * (double precision, as torch.optim.Adam computes them on the host), next dropout seed.
+ *  state: uint32[8]  {t, base_seed, step_seed, -, float step_size, float bc2_sqrt, -, -}
+ */
+int srfrd_step_begin(uint32_t* state, double lr, double beta1, double beta2, void* stream);
+
+/*
+ * Dense Adam over the flat vector [table | dense] (torch.optim.Adam semantics, reference trainer.py:41, :390):
+ *   g = grad[i] * gscale;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= step_size * m / (sqrt(v)/bc2_sqrt + eps)
+ * gscale = 1 / stats[2] if stats != NULL (mean over non-pad targets, trainer.py:36-38) else 1.
+ * The first n_zero gradient elements (the table, accumulated by atomics) are re-zeroed in the same pass.
+ * [i0, i1) = the slice this rank updates (sharded optimizer); pass 0, n for all.
+ */
+int srfrd_adam_step(float* param, float* grad, float* m, float* v, int64_t n, int64_t i0, int64_t i1,
+                    int64_t n_zero, double beta1, double beta2, double eps,
+                    const uint32_t* state, const float* stats, void* stream);
+
+/* loss = stats[0]/stats[2] + stats[1]/stats[2] -> loss_out[0] (reference trainer.py:36-38). */
+int srfrd_loss_finalize(const float* stats, float* loss_out, void* stream);
+
+/* get_Labels (reference SRFR_model.py:546-570) and SRFRN.predict's user label (:244); labels int64 (B).
+ * kind = SRFRD_SRFU_B / _F / _R, or SRFRD_SRFRN for the predict label. */
+int srfrd_user_labels(int kind, const int64_t* fake_ids, int B, int L, int64_t* labels, void* stream);
+
+/*
+ * predict (reference SRFR_model.py:144-152 and twins): logits[b][i] = <hidden[b, L-1, :], E[cand]> with
+ * E = item row (SRFRN: item row || fake_embed[user_label[b]]).  cand is (n_cand) shared by all users
+ * (cand_stride = 0) or (B, n_cand) per user (cand_stride = n_cand).  logits (B, n_cand).
+ */
+int srfrd_predict_logits(const srfrd_layout* lay, const float* item_table, const float* dense,
+                         const float* hidden, int B, int L, const int64_t* cand, int n_cand, int64_t cand_stride,
+                         const int64_t* user_label, float* logits, void* stream);
+
+/*
+ * Full-catalog ranking: top-k items of <hidden[b, L-1, :], E[i]> over i in [item_lo, item_hi) with the logits
+ * never written to HBM.  Ties break to the lower item id (stable descending sort).  topk_idx int64 (B,k),
+ * topk_val (B,k).  workspace: srfrd_topk_workspace_bytes().  exclude_pad != 0 skips item 0.
+ */
+int64_t srfrd_topk_workspace_bytes(int B, int k, int64_t n_rows);
+int srfrd_logits_topk(const srfrd_layout* lay, const float* item_table, const float* dense,
+                      const float* hidden, int B, int L, int64_t item_lo, int64_t item_hi, int exclude_pad,
+                      const int64_t* user_label, int k, int64_t* topk_idx, float* topk_val,
+                      void* workspace, void* stream);
+
+/* HR@10 / NDCG@10 inputs (reference utils.py:589-597): rank[b] = #{i >= 1 : logits[b][i] > logits[b][0]};
+ * metric_acc[0] += [rank<10] / log2(rank+2), metric_acc[1] += [rank<10], metric_acc[2] += 1 (double[3]). */
+int srfrd_eval_rank(const float* logits, int B, int n_cand, int32_t* rank, double* metric_acc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRFRD_HIP_H */

@@ -1,0 +1,12 @@
+"""srfrd_amd: the SRFRD sequential-recommender hot path on MI355X (gfx950).
+
+Drop-in module classes (same constructors / forward / predict / state_dict as the reference's SRFR_model.py), a fused
+train step, batched evaluation and a synthetic sampler, all on top of the C ABI in include/srfrd_hip.h.
+"""
+from .modules import SASRec, SRFR, SRFRN, SRFU, SRFU_B, SRFU_F, SRFU_R  # noqa: F401
+from .trainer import FusedTrainer, flat_allreduce, shard_bounds  # noqa: F401
+from .evaluate import evaluate_batches, ranks_from_logits  # noqa: F401
+from .sampler import synthetic_batch, eval_candidates  # noqa: F401
+
+__all__ = ["SASRec", "SRFR", "SRFRN", "SRFU", "SRFU_B", "SRFU_F", "SRFU_R", "FusedTrainer", "flat_allreduce",
+           "shard_bounds", "evaluate_batches", "ranks_from_logits", "synthetic_batch", "eval_candidates"]

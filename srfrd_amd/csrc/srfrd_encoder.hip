@@ -1,0 +1,813 @@
+// Fused SRFRD encoder forward / backward for MI355X (gfx950).
+//
+// One persistent workgroup walks sequences b = blockIdx.x, blockIdx.x + gridDim.x, ...; the whole
+// per-sequence working set (embedded inputs, LN outputs, Q/K/V, the L x L scores, FFN hidden) stays in
+// LDS between phases, so HBM sees only ids, the gathered embedding rows, the outputs and (training) the
+// per-block checkpoints.  Reference arithmetic being reproduced: SURVEY.md 3.4 / reference
+// SRFR_model.py:92-142 (SRFR), :192-239 (SRFRN), :473-530 (SRFU_*), :621-666 (SASRec); torch
+// multi_head_attention_forward explicit path (q from LN(x), k = v from x, q * sqrt(1/d_h), additive causal
+// -inf mask, softmax, dropout on P, P v, out_proj); residuals on the LayerNormed tensors; eps = 1e-8.
+#include "srfrd_dev.h"
+
+namespace srfrd {
+
+struct EncArgs {
+  srfrd_layout lay;
+  const float* table;
+  const float* dense;
+  const int64_t *in_ids, *fk_ids, *pos_ids, *pos_fk, *neg_ids, *neg_fk;
+  int B, L;
+  uint32_t seed;
+  const uint32_t* seed_dev;
+  uint32_t drop_thr;
+  float drop_scale;
+  int drop_on;
+  int64_t seq0;
+  float qscale;
+  // forward outputs
+  float *hidden, *pos_logits, *neg_logits, *save_x, *save_h1, *loss_part;
+  // backward inputs / outputs
+  const float *c_hidden, *c_pl, *c_nl, *c_save_x, *c_save_h1, *d_hidden, *d_pos, *d_neg;
+  int fused_bce;
+  float *grad_table, *grad_slabs;
+  // debug taps
+  float* dbg;
+  int dbg_seq;
+  int64_t dbg_slot;
+};
+
+__device__ __forceinline__ void tap(const EncArgs& a, int b, int slot, const float* buf, int rows, int cols, int ld) {
+  if (a.dbg == nullptr || b != a.dbg_seq) return;
+  float* dst = a.dbg + (int64_t)slot * a.dbg_slot;
+  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+    const int r = i / cols, c = i - r * cols;
+    dst[i] = buf[r * ld + c];
+  }
+}
+
+// user label of one sequence from its fake/real ids (reference SRFR_model.py:546-570); wave-uniform result
+__device__ __forceinline__ int user_label_wave(int kind, const int64_t* fk_row, int L, int n_labels) {
+  const int lane = threadIdx.x & 63;
+  int n1 = 0, n2 = 0;
+  if (fk_row != nullptr)
+    for (int t = lane; t < L; t += 64) {
+      const int f = (int)fk_row[t];
+      n1 += (f == 1);
+      n2 += (f == 2);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n1 += __shfl_xor(n1, o, 64);
+    n2 += __shfl_xor(n2, o, 64);
+  }
+  int lab;
+  if (kind == SRFRD_SRFU_B) lab = (n1 < n2) ? 1 : 2;                       // round-half-even(1.5) = 2 on ties
+  else if (kind == SRFRD_SRFU_F) lab = n1;
+  else if (kind == SRFRD_SRFU_R) {
+    const int tot = n1 + n2;                                               // all-pad row: reference is 0/0; guarded to 0
+    lab = tot == 0 ? 0 : (int)floorf(((float)n1 / (float)tot) * 10.0f);
+  } else lab = (n1 > n2) ? 2 : 1;                                          // SRFRN.predict: int() truncation, tie -> 1
+  if (n_labels > 0) lab = min(max(lab, 0), n_labels - 1);
+  return lab;
+}
+
+// ================================================================================================
+// forward
+// ================================================================================================
+__global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const srfrd_layout& ly = a.lay;
+  const Geom g = make_geom(a.L, ly.D);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nthr = blockDim.x;
+  const int L = g.L, LP = g.LP, D = g.D, DS = g.DS, SLD = g.SLD, NT = g.NT, MT = g.MT, DK = g.DK;
+  const int szA = LP * DS, szX = imax(szA, LP * SLD);
+  float* bXS = smem;
+  float* bQN = bXS + szX;
+  float* bQ = bQN + szA;
+  float* bK = bQ + szA;
+  float* bV = bK + szA;
+  float* tail = bV + szA + kSlack;
+  int* s_in = (int*)tail;
+  float* s_keep = tail + LP;
+  int* s_pid = (int*)(tail + 2 * LP);
+  int* s_nid = (int*)(tail + 3 * LP);
+  float* s_misc = tail + 4 * LP;          // 64 floats
+  {
+    const int total = (int)fwd_lds_floats(g);
+    for (int i = tid; i < total; i += nthr) smem[i] = 0.f;
+  }
+  __syncthreads();
+
+  const float* P = a.dense;
+  const float* table = a.table;
+  const int kind = ly.kind;
+  const bool is_sas = kind == SRFRD_SASREC;
+  const bool has_fake = kind == SRFRD_SRFR || kind == SRFRD_SRFRN;
+  const bool is_srfu = kind >= SRFRD_SRFU_B;
+  const int di = ly.d_item, dfk = ly.d_fake, dout = ly.d_out;
+  const float sqrtD = sqrtf((float)di);
+  const float qscale = a.qscale;
+  const uint32_t seed = a.seed_dev ? *a.seed_dev : a.seed;
+  const int B = a.B;
+
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int64_t rowbase = (int64_t)b * L;
+    const uint32_t seq = (uint32_t)(a.seq0 + b);
+    for (int t = tid; t < LP; t += nthr) {
+      const int id = t < L ? (int)a.in_ids[rowbase + t] : 0;
+      s_in[t] = id;
+      s_keep[t] = id != 0 ? 1.f : 0.f;
+      s_pid[t] = (t < L && a.pos_ids) ? (int)a.pos_ids[rowbase + t] : 0;
+      s_nid[t] = (t < L && a.neg_ids) ? (int)a.neg_ids[rowbase + t] : 0;
+    }
+    if (is_srfu && wave == 0) {
+      const int lab = user_label_wave(kind, a.fk_ids ? a.fk_ids + rowbase : nullptr, L, ly.n_labels);
+      if (lane == 0) ((int*)s_misc)[0] = lab;
+    }
+    __syncthreads();
+
+    // ---- embedding: gather + position (+ side channel) + pad mask          
+    {
+      const DropSite dsE = drop_site(a.drop_on && is_sas, seed, SITE_EMB, seq, a.drop_thr, a.drop_scale);
+      const int lab = is_srfu ? ((int*)s_misc)[0] : 0;
+      for (int t = wave; t < L; t += nw) {
+        if (lane < D) {
+          const int id = s_in[t];
+          float v;
+          if (has_fake) {
+            if (lane < di) v = table[(int64_t)id * di + lane] + P[ly.off_pos + t * di + lane];
+            else {
+              const int f = a.fk_ids ? (int)a.fk_ids[rowbase + t] : 0;
+              v = P[ly.off_side + f * dfk + (lane - di)];
+            }
+          } else {
+            v = table[(int64_t)id * di + lane];
+            if (is_sas) v *= sqrtD;
+            v += P[ly.off_pos + t * di + lane];
+            if (is_srfu) v += P[ly.off_side + lab * D + lane];
+            if (is_sas) v *= drop_mul(dsE, t, lane);
+          }
+          v *= s_keep[t];
+          bXS[t * DS + lane] = v;
+          if (a.save_x) a.save_x[(rowbase + t) * D + lane] = v;
+        }
+      }
+    }
+    __syncthreads();
+    tap(a, b, 0, bXS, L, D, DS);
+
+    for (int i = 0; i < ly.n_blocks; ++i) {
+      const srfrd_block_off o = ly.blk[i];
+      const int tb = 1 + 8 * i;
+      ln_rows(bXS, bQN, L, DS, D, P + o.ln1_w, P + o.ln1_b);
+      __syncthreads();
+      tap(a, b, tb + 0, bQN, L, D, DS);
+      // q = (LN(x) Wq^T + bq) * sqrt(1/d_h);  k = x Wk^T + bk;  v = x Wv^T + bv
+      gemm_tiles<0>(MT, NT, DK, Mat{bQN, DS}, WgtNT{P + o.in_w, D, D},
+                    [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = (v + P[o.in_b + c]) * qscale; });
+      gemm_tiles<0>(MT, NT, DK, Mat{bXS, DS}, WgtNT{P + o.in_w + D * D, D, D},
+                    [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v + P[o.in_b + D + c]; });
+      gemm_tiles<0>(MT, NT, DK, Mat{bXS, DS}, WgtNT{P + o.in_w + 2 * D * D, D, D},
+                    [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v + P[o.in_b + 2 * D + c]; });
+      __syncthreads();
+      tap(a, b, tb + 1, bQ, L, D, DS);
+      tap(a, b, tb + 2, bK, L, D, DS);
+      tap(a, b, tb + 3, bV, L, D, DS);
+      // S = q k^T on the lower-triangular tiles (x is dead: S overlays it)
+      gemm_tiles<1>(MT, MT, DK, Mat{bQ, DS}, MatT{bK, DS}, [&](int r, int c, float v) { bXS[r * SLD + c] = v; });
+      __syncthreads();
+      // causal softmax (+ attention dropout); keys j > r get exact zeros up to LP
+      {
+        const DropSite dsA = drop_site(a.drop_on, seed, site_attn(i), seq, a.drop_thr, a.drop_scale);
+        for (int r = wave; r < L; r += nw) {
+          float* row = bXS + r * SLD;
+          float m = -INFINITY;
+          for (int j = lane; j <= r; j += 64) m = fmaxf(m, row[j]);
+          m = wave_max(m);
+          float s = 0.f;
+          for (int j = lane; j <= r; j += 64) {
+            const float e = expf(row[j] - m);
+            row[j] = e;
+            s += e;
+          }
+          s = wave_sum(s);
+          for (int j = lane; j < LP; j += 64) row[j] = j <= r ? (row[j] / s) * drop_mul(dsA, r, j) : 0.f;
+        }
+      }
+      __syncthreads();
+      tap(a, b, tb + 4, bXS, L, L, SLD);
+      // o = P v  (q is dead: o overlays it)
+      gemm_tiles<2>(MT, NT, LP, Mat{bXS, SLD}, Mat{bV, DS}, [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v; });
+      __syncthreads();
+      // h1 = LN(x) + (o Wo^T + bo)
+      gemm_tiles<0>(MT, NT, DK, Mat{bQ, DS}, WgtNT{P + o.out_w, D, D}, [&](int r, int c, float v) {
+        if (c < D) {
+          const float h = bQN[r * DS + c] + (v + P[o.out_b + c]);
+          bXS[r * DS + c] = h;
+          if (a.save_h1 && r < L) a.save_h1[((int64_t)i * B * L + rowbase + r) * D + c] = h;
+        }
+      });
+      __syncthreads();
+      tap(a, b, tb + 5, bXS, L, D, DS);
+      ln_rows(bXS, bQN, L, DS, D, P + o.ln2_w, P + o.ln2_b);
+      __syncthreads();
+      tap(a, b, tb + 6, bQN, L, D, DS);
+      // PW-FFN: y = (drop2(relu(drop1(h2 W1^T + b1)) W2^T + b2) + h2) * keep
+      const DropSite ds1 = drop_site(a.drop_on, seed, site_ffn1(i), seq, a.drop_thr, a.drop_scale);
+      const DropSite ds2 = drop_site(a.drop_on, seed, site_ffn2(i), seq, a.drop_thr, a.drop_scale);
+      gemm_tiles<0>(MT, NT, DK, Mat{bQN, DS}, WgtNT{P + o.c1_w, D, D}, [&](int r, int c, float v) {
+        if (c < D) bQ[r * DS + c] = fmaxf((v + P[o.c1_b + c]) * drop_mul(ds1, r, c), 0.f);
+      });
+      __syncthreads();
+      gemm_tiles<0>(MT, NT, DK, Mat{bQ, DS}, WgtNT{P + o.c2_w, D, D}, [&](int r, int c, float v) {
+        if (c < D) {
+          const float y = ((v + P[o.c2_b + c]) * drop_mul(ds2, r, c) + bQN[r * DS + c]) * s_keep[r];
+          bXS[r * DS + c] = y;
+          if (a.save_x && r < L) a.save_x[((int64_t)(i + 1) * B * L + rowbase + r) * D + c] = y;
+        }
+      });
+      __syncthreads();
+      tap(a, b, tb + 7, bXS, L, D, DS);
+    }
+
+    // ---- head: (last_conv) -> last LayerNorm -> hidden, pos/neg logits, BCE partial sums
+    const float* hin = bXS;
+    if (kind == SRFRD_SRFR) {
+      gemm_tiles<0>(MT, (di + 15) >> 4, DK, Mat{bXS, DS}, WgtNT{P + ly.off_lc_w, di, D},
+                    [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v + P[ly.off_lc_b + c]; });
+      __syncthreads();
+      hin = bQ;
+    }
+    ln_rows(hin, bQN, L, DS, dout, P + ly.off_ll_w, P + ly.off_ll_b);
+    __syncthreads();
+    {
+      float sp = 0.f, sn = 0.f, cnt = 0.f;
+      for (int t = wave; t < L; t += nw) {
+        const float h = lane < dout ? bQN[t * DS + lane] : 0.f;
+        if (lane < dout) a.hidden[(rowbase + t) * dout + lane] = h;
+        float pl = 0.f, nl = 0.f;
+        if (a.pos_ids) {
+          const int pid = s_pid[t];
+          float e = 0.f;
+          if (lane < di) e = table[(int64_t)pid * di + lane];
+          else if (kind == SRFRD_SRFRN && lane < D) e = P[ly.off_side + (int)a.pos_fk[rowbase + t] * dfk + (lane - di)];
+          pl = wave_sum(h * e);
+          if (lane == 0) a.pos_logits[rowbase + t] = pl;
+        }
+        if (a.neg_ids) {
+          const int nid = s_nid[t];
+          float e = 0.f;
+          if (lane < di) e = table[(int64_t)nid * di + lane];
+          else if (kind == SRFRD_SRFRN && lane < D) e = P[ly.off_side + (int)a.neg_fk[rowbase + t] * dfk + (lane - di)];
+          nl = wave_sum(h * e);
+          if (lane == 0) a.neg_logits[rowbase + t] = nl;
+        }
+        if (a.loss_part && s_pid[t] != 0) {      // trainer.py:36-38: both terms indexed by pos != 0
+          sp += softplus_f(-pl);
+          sn += softplus_f(nl);
+          cnt += 1.f;
+        }
+      }
+      if (a.loss_part) {
+        if (lane == 0) {
+          s_misc[8 + wave * 3 + 0] = sp;
+          s_misc[8 + wave * 3 + 1] = sn;
+          s_misc[8 + wave * 3 + 2] = cnt;
+        }
+        __syncthreads();
+        if (tid < 3) {
+          float s = 0.f;
+          for (int w = 0; w < nw; ++w) s += s_misc[8 + w * 3 + tid];
+          a.loss_part[(int64_t)b * 3 + tid] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ================================================================================================
+// backward
+// ================================================================================================
+// column sums over rows < L of an LDS matrix, added into a slab vector by ONE wave (fixed owner => the
+// read-modify-write on the slab is race-free and order-deterministic)
+__device__ __forceinline__ void colsum_to_slab(int owner_wave, const float* buf, int ld, int rows, int cols, float* dst) {
+  if ((int)(threadIdx.x >> 6) != owner_wave) return;
+  const int lane = threadIdx.x & 63;
+  if (lane < cols) {
+    float s = 0.f;
+    for (int t = 0; t < rows; ++t) s += buf[t * ld + lane];
+    dst[lane] += s;
+  }
+}
+
+// per-wave (dgamma, dbeta) partials -> LDS -> wave 0 sums in wave order -> slab
+__device__ __forceinline__ void ln_param_grads_to_slab(float* s_red, float dg, float db, int cols, float* dst_w, float* dst_b) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  s_red[(wave * 2 + 0) * 64 + lane] = dg;
+  s_red[(wave * 2 + 1) * 64 + lane] = db;
+  __syncthreads();
+  if (wave == 0 && lane < cols) {
+    float sg = 0.f, sb = 0.f;
+    for (int w = 0; w < nw; ++w) {
+      sg += s_red[(w * 2 + 0) * 64 + lane];
+      sb += s_red[(w * 2 + 1) * 64 + lane];
+    }
+    dst_w[lane] += sg;
+    dst_b[lane] += sb;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const srfrd_layout& ly = a.lay;
+  const Geom g = make_geom(a.L, ly.D);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nthr = blockDim.x;
+  const int L = g.L, LP = g.LP, D = g.D, DS = g.DS, SLD = g.SLD, NT = g.NT, MT = g.MT, DK = g.DK;
+  const int szA = LP * DS, szS = imax(LP * SLD, szA);
+  float* bX = smem;
+  float* bQN = bX + szA;
+  float* bQ = bQN + szA;
+  float* bK = bQ + szA;
+  float* bV = bK + szA;
+  float* bO = bV + szA;
+  float* bG = bO + szA;
+  float* bT = bG + szA;
+  float* S1 = bT + szA;
+  float* S2 = S1 + szS;
+  float* tail = S2 + szS + kSlack;
+  int* s_in = (int*)tail;
+  float* s_keep = tail + LP;
+  int* s_pid = (int*)(tail + 2 * LP);
+  int* s_nid = (int*)(tail + 3 * LP);
+  int* s_fk = (int*)(tail + 4 * LP);
+  int* s_pfk = (int*)(tail + 5 * LP);
+  int* s_nfk = (int*)(tail + 6 * LP);
+  float* s_dpl = tail + 7 * LP;
+  float* s_dnl = tail + 8 * LP;
+  float* s_misc = tail + 10 * LP;        // 64
+  float* s_red = s_misc + 64;            // 8 waves x 2 x 64
+  {
+    const int total = (int)bwd_lds_floats(g);
+    for (int i = tid; i < total; i += nthr) smem[i] = 0.f;
+  }
+  const float* P = a.dense;
+  const float* table = a.table;
+  const int kind = ly.kind;
+  const bool is_sas = kind == SRFRD_SASREC;
+  const bool has_fake = kind == SRFRD_SRFR || kind == SRFRD_SRFRN;
+  const bool is_srfu = kind >= SRFRD_SRFU_B;
+  const int di = ly.d_item, dfk = ly.d_fake, dout = ly.d_out;
+  const float sqrtD = sqrtf((float)di);
+  const float qscale = a.qscale;
+  const uint32_t seed = a.seed_dev ? *a.seed_dev : a.seed;
+  const int B = a.B;
+  float* slab = a.grad_slabs + (int64_t)blockIdx.x * ly.n_dense;
+  for (int64_t i = tid; i < ly.n_dense; i += nthr) slab[i] = 0.f;
+  __syncthreads();
+  auto slab_rmw = [&](int64_t off, int R, int C) {
+    return [=](int r, int c, float v) { if (r < R && c < C) slab[off + r * C + c] += v; };
+  };
+  const float keep_scale = a.drop_on ? a.drop_scale : 1.0f;
+
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int64_t rowbase = (int64_t)b * L;
+    const uint32_t seq = (uint32_t)(a.seq0 + b);
+    for (int t = tid; t < LP; t += nthr) {
+      const bool in = t < L;
+      const int id = in ? (int)a.in_ids[rowbase + t] : 0;
+      const int pid = (in && a.pos_ids) ? (int)a.pos_ids[rowbase + t] : 0;
+      const int nid = (in && a.neg_ids) ? (int)a.neg_ids[rowbase + t] : 0;
+      s_in[t] = id;
+      s_keep[t] = id != 0 ? 1.f : 0.f;
+      s_pid[t] = pid;
+      s_nid[t] = nid;
+      s_fk[t] = (in && a.fk_ids) ? (int)a.fk_ids[rowbase + t] : 0;
+      s_pfk[t] = (in && a.pos_fk) ? (int)a.pos_fk[rowbase + t] : 0;
+      s_nfk[t] = (in && a.neg_fk) ? (int)a.neg_fk[rowbase + t] : 0;
+      float dp = 0.f, dn = 0.f;
+      if (in) {
+        if (a.fused_bce) {
+          if (pid != 0) {
+            dp = sigmoid_f(a.c_pl[rowbase + t]) - 1.0f;
+            dn = sigmoid_f(a.c_nl[rowbase + t]);
+          }
+        } else {
+          if (a.d_pos) dp = a.d_pos[rowbase + t];
+          if (a.d_neg) dn = a.d_neg[rowbase + t];
+        }
+      }
+      s_dpl[t] = dp;
+      s_dnl[t] = dn;
+    }
+    if (is_srfu && wave == 0) {
+      const int lab = user_label_wave(kind, a.fk_ids ? a.fk_ids + rowbase : nullptr, L, ly.n_labels);
+      if (lane == 0) ((int*)s_misc)[0] = lab;
+    }
+    // final block output (input of last_conv / last LayerNorm) -> bX ; gradient pad rows must be exact zeros
+    for (int i = tid; i < L * D; i += nthr) {
+      const int t = i / D, c = i - t * D;
+      bX[t * DS + c] = a.c_save_x[((int64_t)ly.n_blocks * B * L + rowbase + t) * D + c];
+    }
+    for (int i = tid; i < (LP - L) * DS; i += nthr) bG[L * DS + i] = 0.f;
+    __syncthreads();
+
+    const float* lnin = bX;
+    if (kind == SRFRD_SRFR) {
+      gemm_tiles<0>(MT, (di + 15) >> 4, DK, Mat{bX, DS}, WgtNT{P + ly.off_lc_w, di, D},
+                    [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v + P[ly.off_lc_b + c]; });
+      __syncthreads();
+      lnin = bQ;
+    }
+    // ---- logits backward: dh, item-table scatter (float atomics; row 0 = padding_idx gets none)
+    for (int t = wave; t < L; t += nw) {
+      const float dp = s_dpl[t], dn = s_dnl[t];
+      const int pid = s_pid[t], nid = s_nid[t];
+      float h = 0.f, dh = 0.f;
+      if (lane < dout) {
+        h = a.c_hidden[(rowbase + t) * dout + lane];
+        if (a.d_hidden) dh = a.d_hidden[(rowbase + t) * dout + lane];
+      }
+      if (lane < di) {
+        if (a.pos_ids) {
+          dh += dp * table[(int64_t)pid * di + lane];
+          if (pid != 0 && dp != 0.f) atomicAdd(&a.grad_table[(int64_t)pid * di + lane], dp * h);
+        }
+        if (a.neg_ids) {
+          dh += dn * table[(int64_t)nid * di + lane];
+          if (nid != 0 && dn != 0.f) atomicAdd(&a.grad_table[(int64_t)nid * di + lane], dn * h);
+        }
+      } else if (kind == SRFRD_SRFRN && lane < D) {
+        if (a.pos_ids) dh += dp * P[ly.off_side + s_pfk[t] * dfk + (lane - di)];
+        if (a.neg_ids) dh += dn * P[ly.off_side + s_nfk[t] * dfk + (lane - di)];
+        bT[t * DS + lane] = h;            // kept for the fake_embed gradient pass below
+      }
+      if (lane < D) bG[t * DS + lane] = lane < dout ? dh : 0.f;
+    }
+    __syncthreads();
+    if (kind == SRFRD_SRFRN && wave == (1 % nw) && lane < dfk && (a.pos_ids || a.neg_ids)) {
+      for (int f = 1; f <= 2; ++f) {      // fake_embed rows 1 (fake) and 2 (real); row 0 is padding_idx
+        float s = 0.f;
+        for (int t = 0; t < L; ++t) {
+          const float w = (s_pfk[t] == f ? s_dpl[t] : 0.f) + (s_nfk[t] == f ? s_dnl[t] : 0.f);
+          s += w * bT[t * DS + di + lane];
+        }
+        slab[ly.off_side + f * dfk + lane] += s;
+      }
+    }
+    // ---- last LayerNorm backward (in place in bG)
+    {
+      float dg = 0.f, db = 0.f;
+      ln_bwd_rows<false>(bG, lnin, bG, L, DS, dout, P + ly.off_ll_w, dg, db);
+      ln_param_grads_to_slab(s_red, dg, db, dout, slab + ly.off_ll_w, slab + ly.off_ll_b);
+    }
+    if (kind == SRFRD_SRFR) {             // hc = hf Wlc^T + blc
+      gemm_tiles<0>((di + 15) >> 4, NT, LP, MatT{bG, DS}, Mat{bX, DS}, slab_rmw(ly.off_lc_w, di, D));
+      colsum_to_slab(0, bG, DS, L, di, slab + ly.off_lc_b);
+      gemm_tiles<0>(MT, NT, (di + 3) & ~3, Mat{bG, DS}, WgtNN{P + ly.off_lc_w, di, D},
+                    [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });
+      __syncthreads();
+      float* t_ = bG; bG = bT; bT = t_;
+    }
+    tap(a, b, 0, bG, L, D, DS);
+
+    for (int i = ly.n_blocks - 1; i >= 0; --i) {
+      const srfrd_block_off o = ly.blk[i];
+      const int tb = 1 + 4 * i;
+      const DropSite dsA = drop_site(a.drop_on, seed, site_attn(i), seq, a.drop_thr, a.drop_scale);
+      const DropSite ds1 = drop_site(a.drop_on, seed, site_ffn1(i), seq, a.drop_thr, a.drop_scale);
+      const DropSite ds2 = drop_site(a.drop_on, seed, site_ffn2(i), seq, a.drop_thr, a.drop_scale);
+      // ================= FFN half: y = (drop2(a2) + h2) * keep, a2 = relu(drop1(h2 W1^T + b1)) W2^T + b2
+      for (int idx = tid; idx < L * D; idx += nthr) {
+        const int t = idx / D, c = idx - t * D;
+        bG[t * DS + c] *= s_keep[t];
+        bX[t * DS + c] = a.c_save_h1[((int64_t)i * B * L + rowbase + t) * D + c];
+      }
+      __syncthreads();
+      ln_rows(bX, bQN, L, DS, D, P + o.ln2_w, P + o.ln2_b);                        // h2
+      for (int idx = tid; idx < LP * D; idx += nthr) {                             // dA2 = drop2'(dy)
+        const int t = idx / D, c = idx - t * D;
+        bK[t * DS + c] = t < L ? bG[t * DS + c] * drop_mul(ds2, t, c) : 0.f;
+      }
+      __syncthreads();
+      gemm_tiles<0>(MT, NT, DK, Mat{bQN, DS}, WgtNT{P + o.c1_w, D, D}, [&](int r, int c, float v) {
+        if (c < D) bQ[r * DS + c] = fmaxf((v + P[o.c1_b + c]) * drop_mul(ds1, r, c), 0.f);   // r = relu(drop1(a1))
+      });
+      __syncthreads();
+      gemm_tiles<0>(NT, NT, LP, MatT{bK, DS}, Mat{bQ, DS}, slab_rmw(o.c2_w, D, D));           // dW2 += dA2^T r
+      colsum_to_slab(0, bK, DS, L, D, slab + o.c2_b);
+      gemm_tiles<0>(MT, NT, DK, Mat{bK, DS}, WgtNN{P + o.c2_w, D, D}, [&](int r, int c, float v) {
+        if (c < D) bV[r * DS + c] = bQ[r * DS + c] > 0.f ? v * keep_scale : 0.f;               // dA1
+      });
+      __syncthreads();
+      gemm_tiles<0>(NT, NT, LP, MatT{bV, DS}, Mat{bQN, DS}, slab_rmw(o.c1_w, D, D));           // dW1 += dA1^T h2
+      colsum_to_slab(1 % nw, bV, DS, L, D, slab + o.c1_b);
+      gemm_tiles<0>(MT, NT, DK, Mat{bV, DS}, WgtNN{P + o.c1_w, D, D},
+                    [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });           // dh2 = dy + dA1 W1
+      __syncthreads();
+      {
+        float dg = 0.f, db = 0.f;
+        ln_bwd_rows<false>(bG, bX, bG, L, DS, D, P + o.ln2_w, dg, db);                         // dh1
+        ln_param_grads_to_slab(s_red, dg, db, D, slab + o.ln2_w, slab + o.ln2_b);
+      }
+      tap(a, b, tb + 0, bG, L, D, DS);
+      // ================= attention half: h1 = LN1(x) + (P v) Wo^T + bo
+      for (int idx = tid; idx < L * D; idx += nthr) {
+        const int t = idx / D, c = idx - t * D;
+        bX[t * DS + c] = a.c_save_x[((int64_t)i * B * L + rowbase + t) * D + c];
+      }
+      __syncthreads();
+      ln_rows(bX, bQN, L, DS, D, P + o.ln1_w, P + o.ln1_b);
+      __syncthreads();
+      gemm_tiles<0>(MT, NT, DK, Mat{bQN, DS}, WgtNT{P + o.in_w, D, D},
+                    [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = (v + P[o.in_b + c]) * qscale; });
+      gemm_tiles<0>(MT, NT, DK, Mat{bX, DS}, WgtNT{P + o.in_w + D * D, D, D},
+                    [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v + P[o.in_b + D + c]; });
+      gemm_tiles<0>(MT, NT, DK, Mat{bX, DS}, WgtNT{P + o.in_w + 2 * D * D, D, D},
+                    [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v + P[o.in_b + 2 * D + c]; });
+      __syncthreads();
+      gemm_tiles<1>(MT, MT, DK, Mat{bQ, DS}, MatT{bK, DS}, [&](int r, int c, float v) { S1[r * SLD + c] = v; });
+      __syncthreads();
+      for (int r = wave; r < L; r += nw) {                       // P (dropout NOT folded in: applied on load)
+        float* row = S1 + r * SLD;
+        float m = -INFINITY;
+        for (int j = lane; j <= r; j += 64) m = fmaxf(m, row[j]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int j = lane; j <= r; j += 64) {
+          const float e = expf(row[j] - m);
+          row[j] = e;
+          s += e;
+        }
+        s = wave_sum(s);
+        for (int j = lane; j < LP; j += 64) row[j] = j <= r ? row[j] / s : 0.f;
+      }
+      __syncthreads();
+      gemm_tiles<2>(MT, NT, LP, MatDrop{S1, SLD, dsA}, Mat{bV, DS},
+                    [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });            // o = drop(P) v
+      __syncthreads();
+      gemm_tiles<0>(NT, NT, LP, MatT{bG, DS}, Mat{bO, DS}, slab_rmw(o.out_w, D, D));           // dWo += dh1^T o
+      colsum_to_slab(2 % nw, bG, DS, L, D, slab + o.out_b);
+      __syncthreads();
+      gemm_tiles<0>(MT, NT, DK, Mat{bG, DS}, WgtNN{P + o.out_w, D, D},
+                    [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });            // do = dh1 Wo
+      __syncthreads();
+      gemm_tiles<1>(MT, MT, DK, Mat{bO, DS}, MatT{bV, DS}, [&](int r, int c, float v) { S2[r * SLD + c] = v; });  // dPd = do v^T
+      gemm_tiles<3>(MT, NT, LP, MatDropT{S1, SLD, dsA}, Mat{bO, DS},
+                    [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });            // dv = drop(P)^T do
+      __syncthreads();
+      for (int r = wave; r < LP; r += nw) {                      // dS = P * (dP - sum_j dP_j P_j), dP = mask * dPd
+        float* drow = S2 + r * SLD;
+        if (r < L) {
+          const float* prow = S1 + r * SLD;
+          float acc = 0.f;
+          for (int j = lane; j <= r; j += 64) {
+            const float dp = drow[j] * drop_mul(dsA, r, j);
+            drow[j] = dp;
+            acc += dp * prow[j];
+          }
+          acc = wave_sum(acc);
+          for (int j = lane; j < LP; j += 64) drow[j] = j <= r ? prow[j] * (drow[j] - acc) : 0.f;
+        } else {
+          for (int j = lane; j < LP; j += 64) drow[j] = 0.f;
+        }
+      }
+      __syncthreads();
+      float* dKb = S1;                                           // P is dead: dk overlays it as [LP][DS]
+      gemm_tiles<2>(MT, NT, LP, Mat{S2, SLD}, Mat{bK, DS},
+                    [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v * qscale; });   // dq (pre-scale)
+      gemm_tiles<3>(MT, NT, LP, MatT{S2, SLD}, Mat{bQ, DS},
+                    [&](int r, int c, float v) { if (c < D) dKb[r * DS + c] = v; });           // dk = dS^T q
+      __syncthreads();
+      gemm_tiles<0>(NT, NT, LP, MatT{bO, DS}, Mat{bQN, DS}, slab_rmw(o.in_w, D, D));           // dWq
+      colsum_to_slab(0, bO, DS, L, D, slab + o.in_b);
+      gemm_tiles<0>(NT, NT, LP, MatT{dKb, DS}, Mat{bX, DS}, slab_rmw(o.in_w + D * D, D, D));   // dWk
+      colsum_to_slab(1 % nw, dKb, DS, L, D, slab + o.in_b + D);
+      gemm_tiles<0>(NT, NT, LP, MatT{bT, DS}, Mat{bX, DS}, slab_rmw(o.in_w + 2 * D * D, D, D));  // dWv
+      colsum_to_slab(2 % nw, bT, DS, L, D, slab + o.in_b + 2 * D);
+      gemm_tiles<0>(MT, NT, DK, Mat{bO, DS}, WgtNN{P + o.in_w, D, D},
+                    [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });           // dLN1 = dh1 + dq Wq
+      gemm_tiles<0>(MT, NT, DK, Mat{dKb, DS}, WgtNN{P + o.in_w + D * D, D, D},
+                    [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v; });            // dx  = dk Wk
+      gemm_tiles<0>(MT, NT, DK, Mat{bT, DS}, WgtNN{P + o.in_w + 2 * D * D, D, D},
+                    [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] += v; });           //     + dv Wv
+      __syncthreads();
+      {
+        float dg = 0.f, db = 0.f;
+        ln_bwd_rows<true>(bG, bX, bQ, L, DS, D, P + o.ln1_w, dg, db);                          //     + LN1 bwd
+        ln_param_grads_to_slab(s_red, dg, db, D, slab + o.ln1_w, slab + o.ln1_b);
+      }
+      float* t_ = bG; bG = bQ; bQ = t_;
+      tap(a, b, tb + 1, bG, L, D, DS);
+    }
+
+    // ---- embedding backward: item rows (atomics), position table, side channel
+    {
+      const DropSite dsE = drop_site(a.drop_on && is_sas, seed, SITE_EMB, seq, a.drop_thr, a.drop_scale);
+      for (int t = wave; t < L; t += nw) {
+        if (lane < D) {
+          float gv = bG[t * DS + lane] * s_keep[t];
+          if (is_sas) gv *= drop_mul(dsE, t, lane);
+          const int id = s_in[t];
+          if (lane < di) {
+            if (id != 0) atomicAdd(&a.grad_table[(int64_t)id * di + lane], is_sas ? gv * sqrtD : gv);
+            slab[ly.off_pos + t * di + lane] += gv;
+          }
+        }
+      }
+      if (has_fake && wave == (1 % nw) && lane < dfk) {
+        for (int f = 1; f <= 2; ++f) {
+          float s = 0.f;
+          for (int t = 0; t < L; ++t)
+            if (s_fk[t] == f) s += bG[t * DS + di + lane] * s_keep[t];
+          slab[ly.off_side + f * dfk + lane] += s;
+        }
+      }
+      if (is_srfu && wave == (1 % nw) && lane < D) {
+        const int lab = ((int*)s_misc)[0];
+        float s = 0.f;
+        for (int t = 0; t < L; ++t) s += bG[t * DS + lane] * s_keep[t];
+        slab[ly.off_side + lab * D + lane] += s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static int g_num_cu = 0;
+static int num_cu() {
+  if (g_num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      g_num_cu = prop.multiProcessorCount;
+    else
+      g_num_cu = 256;
+  }
+  return g_num_cu;
+}
+
+static int fill_args(EncArgs& a, const srfrd_layout* lay, const float* item_table, const float* dense,
+                     const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids, const int64_t* pos_fake,
+                     const int64_t* neg_ids, const int64_t* neg_fake, int B, int L, double dropout_p, uint32_t seed,
+                     const uint32_t* seed_dev, int64_t seq_index0) {
+  if (!lay || !item_table || !dense || !input_ids || B <= 0 || L <= 0) return SRFRD_E_ARG;
+  if (lay->D > SRFRD_MAX_D || lay->n_heads != 1 || lay->n_blocks > SRFRD_MAX_BLOCKS) return SRFRD_E_UNSUPPORTED;
+  if (L > lay->max_len) return SRFRD_E_ARG;
+  if (dropout_p < 0.0 || dropout_p >= 1.0) return SRFRD_E_ARG;
+  if (lay->kind == SRFRD_SRFRN && ((pos_ids && !pos_fake) || (neg_ids && !neg_fake))) return SRFRD_E_ARG;
+  a.lay = *lay;
+  a.table = item_table;
+  a.dense = dense;
+  a.in_ids = input_ids; a.fk_ids = fake_ids; a.pos_ids = pos_ids; a.pos_fk = pos_fake; a.neg_ids = neg_ids; a.neg_fk = neg_fake;
+  a.B = B; a.L = L;
+  a.seed = seed; a.seed_dev = seed_dev;
+  a.drop_on = dropout_p > 0.0;
+  double thr = dropout_p * 4294967296.0;
+  a.drop_thr = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+  a.drop_scale = (float)(1.0 / (1.0 - dropout_p));
+  a.seq0 = seq_index0;
+  a.qscale = (float)sqrt(1.0 / (double)(lay->D / lay->n_heads));
+  return 0;
+}
+
+}  // namespace srfrd
+
+using namespace srfrd;
+
+extern "C" int srfrd_lds_bytes(const srfrd_layout* lay, int L, int64_t* fwd_bytes, int64_t* bwd_bytes) {
+  if (!lay || L <= 0) return SRFRD_E_ARG;
+  const Geom g = make_geom(L, lay->D);
+  const int64_t f = fwd_lds_floats(g) * 4, bw = bwd_lds_floats(g) * 4;
+  if (fwd_bytes) *fwd_bytes = f <= kLdsLimit ? f : 0;
+  if (bwd_bytes) *bwd_bytes = bw <= kLdsLimit ? bw : 0;
+  return 0;
+}
+
+extern "C" int srfrd_bwd_grid(int B) {
+  if (B <= 0) return SRFRD_E_ARG;
+  const int cu = num_cu();
+  return B < cu ? B : cu;
+}
+
+extern "C" int srfrd_debug_shape(const srfrd_layout* lay, int L, int64_t* slot_floats, int32_t* n_slots) {
+  if (!lay || L <= 0) return SRFRD_E_ARG;
+  if (slot_floats) *slot_floats = (int64_t)L * (L > lay->D ? L : lay->D);
+  if (n_slots) *n_slots = 1 + 8 * lay->n_blocks;
+  return 0;
+}
+
+extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const float* dense,
+                                 const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
+                                 const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
+                                 double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
+                                 float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
+                                 float* loss_part, float* dbg, int dbg_seq, void* stream) {
+  EncArgs a = {};
+  int rc = fill_args(a, lay, item_table, dense, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
+                     dropout_p, seed, seed_dev, seq_index0);
+  if (rc) return rc;
+  if (!hidden || (pos_ids && !pos_logits) || (neg_ids && !neg_logits)) return SRFRD_E_ARG;
+  if (loss_part && !(pos_ids && neg_ids)) return SRFRD_E_ARG;
+  a.hidden = hidden; a.pos_logits = pos_logits; a.neg_logits = neg_logits;
+  a.save_x = save_x; a.save_h1 = save_h1; a.loss_part = loss_part;
+  a.dbg = dbg; a.dbg_seq = dbg_seq;
+  srfrd_debug_shape(lay, L, &a.dbg_slot, nullptr);
+  const Geom g = make_geom(L, lay->D);
+  const int64_t lds = fwd_lds_floats(g) * 4;
+  if (lds > kLdsLimit) return SRFRD_E_UNSUPPORTED;
+  static int64_t s_attr = 0;
+  if (lds > s_attr) {
+    if (hipFuncSetAttribute((const void*)encoder_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SRFRD_E_DEVICE;
+    s_attr = lds;
+  }
+  const int per_cu = (int)(kLdsLimit / lds) > 2 ? 2 : (int)(kLdsLimit / lds);
+  int grid = num_cu() * (per_cu < 1 ? 1 : per_cu);
+  if (grid > B) grid = B;
+  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(grid), dim3(256), (size_t)lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const float* dense,
+                                 const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
+                                 const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
+                                 double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
+                                 const float* hidden, const float* pos_logits, const float* neg_logits,
+                                 const float* save_x, const float* save_h1, const float* d_hidden, const float* d_pos,
+                                 const float* d_neg, int fused_bce, float* grad_table, float* grad_slabs, float* dbg,
+                                 int dbg_seq, void* stream) {
+  EncArgs a = {};
+  int rc = fill_args(a, lay, item_table, dense, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
+                     dropout_p, seed, seed_dev, seq_index0);
+  if (rc) return rc;
+  if (!hidden || !save_x || !save_h1 || !grad_table || !grad_slabs) return SRFRD_E_ARG;
+  if (fused_bce && !(pos_ids && neg_ids && pos_logits && neg_logits)) return SRFRD_E_ARG;
+  a.c_hidden = hidden; a.c_pl = pos_logits; a.c_nl = neg_logits; a.c_save_x = save_x; a.c_save_h1 = save_h1;
+  a.d_hidden = d_hidden; a.d_pos = d_pos; a.d_neg = d_neg; a.fused_bce = fused_bce;
+  a.grad_table = grad_table; a.grad_slabs = grad_slabs;
+  a.dbg = dbg; a.dbg_seq = dbg_seq;
+  srfrd_debug_shape(lay, L, &a.dbg_slot, nullptr);
+  const Geom g = make_geom(L, lay->D);
+  const int64_t lds = bwd_lds_floats(g) * 4;
+  if (lds > kLdsLimit) return SRFRD_E_UNSUPPORTED;
+  static int64_t s_attr = 0;
+  if (lds > s_attr) {
+    if (hipFuncSetAttribute((const void*)encoder_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SRFRD_E_DEVICE;
+    s_attr = lds;
+  }
+  const int grid = srfrd_bwd_grid(B);
+  hipLaunchKernelGGL(encoder_bwd_kernel, dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_layout_init(srfrd_layout* lay, int kind, int n_items, int max_len, int d_item, int d_fake,
+                                 int n_labels, int n_blocks, int n_heads) {
+  if (!lay || kind < 0 || kind > SRFRD_SRFU_R || n_items < 1 || max_len < 1 || d_item < 1 || n_blocks < 0 ||
+      n_blocks > SRFRD_MAX_BLOCKS || n_heads < 1)
+    return SRFRD_E_ARG;
+  const bool has_fake = kind == SRFRD_SRFR || kind == SRFRD_SRFRN;
+  const bool is_srfu = kind >= SRFRD_SRFU_B;
+  if (has_fake && d_fake < 1) return SRFRD_E_ARG;
+  if (is_srfu && n_labels < 1) return SRFRD_E_ARG;
+  srfrd_layout l = {};
+  l.kind = kind; l.n_items = n_items; l.max_len = max_len; l.d_item = d_item;
+  l.d_fake = has_fake ? d_fake : 0;
+  l.D = d_item + l.d_fake;
+  l.d_out = kind == SRFRD_SRFR ? d_item : l.D;
+  l.n_labels = is_srfu ? n_labels : 0;
+  l.n_blocks = n_blocks; l.n_heads = n_heads;
+  if (l.D % n_heads != 0) return SRFRD_E_ARG;
+  const int64_t D = l.D;
+  int64_t off = 0;
+  l.off_pos = off; off += (int64_t)max_len * d_item;
+  l.side_rows = has_fake ? 3 : (is_srfu ? n_labels : 0);
+  l.side_cols = has_fake ? d_fake : (is_srfu ? l.D : 0);
+  l.off_side = off; off += (int64_t)l.side_rows * l.side_cols;
+  for (int i = 0; i < n_blocks; ++i) {
+    srfrd_block_off& o = l.blk[i];
+    o.ln1_w = off; off += D; o.ln1_b = off; off += D;
+    o.in_w = off; off += 3 * D * D; o.in_b = off; off += 3 * D;
+    o.out_w = off; off += D * D; o.out_b = off; off += D;
+    o.ln2_w = off; off += D; o.ln2_b = off; off += D;
+    o.c1_w = off; off += D * D; o.c1_b = off; off += D;
+    o.c2_w = off; off += D * D; o.c2_b = off; off += D;
+  }
+  if (kind == SRFRD_SRFR) {
+    l.off_lc_w = off; off += (int64_t)d_item * D;
+    l.off_lc_b = off; off += d_item;
+  } else {
+    l.off_lc_w = -1; l.off_lc_b = -1;
+  }
+  l.off_ll_w = off; off += l.d_out;
+  l.off_ll_b = off; off += l.d_out;
+  l.n_dense = off;
+  l.n_table = (int64_t)(n_items + 1) * d_item;
+  *lay = l;
+  return 0;
+}

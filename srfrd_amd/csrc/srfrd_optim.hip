@@ -1,0 +1,135 @@
+// Gradient reduction, loss finalisation and the dense Adam step (torch.optim.Adam semantics,
+// reference trainer.py:36-41, :390).  All streaming, HBM-bound, float4-wide.
+#include "srfrd_dev.h"
+
+namespace srfrd {
+
+// grad_dense[i] = sum_w slabs[w][i] in slab order (bitwise reproducible); block 0 also reduces the BCE partials.
+__global__ void __launch_bounds__(256) reduce_dense_kernel(const float* __restrict__ slabs, int n_slabs, int64_t n_dense,
+                                                          float* __restrict__ grad_dense, const float* __restrict__ loss_part,
+                                                          int B, float* __restrict__ stats) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_dense) {
+    float s = 0.f;
+    for (int w = 0; w < n_slabs; ++w) s += slabs[(int64_t)w * n_dense + i];
+    grad_dense[i] = s;
+  }
+  if (blockIdx.x == 0 && loss_part != nullptr && stats != nullptr) {
+    __shared__ float red[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+      s0 += loss_part[(int64_t)b * 3 + 0];
+      s1 += loss_part[(int64_t)b * 3 + 1];
+      s2 += loss_part[(int64_t)b * 3 + 2];
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      float s = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w][threadIdx.x];
+      stats[threadIdx.x] = s;
+    }
+    if (threadIdx.x == 3) stats[3] = 0.f;
+  }
+}
+
+__global__ void step_begin_kernel(uint32_t* state, double lr, double b1, double b2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const uint32_t t = state[0] + 1u;
+    state[0] = t;
+    state[2] = step_seed(state[1], t);
+    const double bc1 = 1.0 - pow(b1, (double)t);
+    const double bc2 = 1.0 - pow(b2, (double)t);
+    ((float*)state)[4] = (float)(lr / bc1);
+    ((float*)state)[5] = (float)sqrt(bc2);
+  }
+}
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float eps,
+                                         float step_size, float bc2s) {
+  m = m * b1 + (1.0f - b1) * g;           // exp_avg.lerp_(grad, 1 - beta1) == exp_avg*b1 + (1-b1)*g up to rounding
+  v = v * b2 + ((1.0f - b2) * g) * g;     // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+  const float denom = sqrtf(v) / bc2s + eps;
+  p = p - step_size * (m / denom);
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
+                                                  float* __restrict__ v, int64_t i0, int64_t i1, int64_t n_zero, float b1,
+                                                  float b2, float eps, const uint32_t* __restrict__ state,
+                                                  const float* __restrict__ stats) {
+  const float step_size = ((const float*)state)[4];
+  const float bc2s = ((const float*)state)[5];
+  const float gscale = stats ? 1.0f / stats[2] : 1.0f;
+  // i0 is a multiple of 4 (host guarantees), so float4 lanes are aligned
+  const int64_t nvec = (i1 - i0) >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nvec; q += stride) {
+    const int64_t i = i0 + (q << 2);
+    float4 p4 = *reinterpret_cast<float4*>(param + i);
+    float4 g4 = *reinterpret_cast<const float4*>(grad + i);
+    float4 m4 = *reinterpret_cast<float4*>(m + i);
+    float4 v4 = *reinterpret_cast<float4*>(v + i);
+    adam_one(p4.x, g4.x * gscale, m4.x, v4.x, b1, b2, eps, step_size, bc2s);
+    adam_one(p4.y, g4.y * gscale, m4.y, v4.y, b1, b2, eps, step_size, bc2s);
+    adam_one(p4.z, g4.z * gscale, m4.z, v4.z, b1, b2, eps, step_size, bc2s);
+    adam_one(p4.w, g4.w * gscale, m4.w, v4.w, b1, b2, eps, step_size, bc2s);
+    *reinterpret_cast<float4*>(param + i) = p4;
+    *reinterpret_cast<float4*>(m + i) = m4;
+    *reinterpret_cast<float4*>(v + i) = v4;
+    if (i + 3 < n_zero) *reinterpret_cast<float4*>(grad + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    else if (i < n_zero) for (int k = 0; k < 4; ++k) if (i + k < n_zero) grad[i + k] = 0.f;
+  }
+  // scalar tail
+  const int64_t tail0 = i0 + (nvec << 2);
+  for (int64_t i = tail0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += stride) {
+    float p = param[i], mm = m[i], vv = v[i];
+    adam_one(p, grad[i] * gscale, mm, vv, b1, b2, eps, step_size, bc2s);
+    param[i] = p; m[i] = mm; v[i] = vv;
+    if (i < n_zero) grad[i] = 0.f;
+  }
+}
+
+__global__ void loss_finalize_kernel(const float* stats, float* loss_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) loss_out[0] = stats[0] / stats[2] + stats[1] / stats[2];
+}
+
+}  // namespace srfrd
+
+using namespace srfrd;
+
+extern "C" int srfrd_reduce_dense(const float* grad_slabs, int n_slabs, int64_t n_dense, float* grad_dense,
+                                  const float* loss_part, int B, float* stats, void* stream) {
+  if (!grad_slabs || !grad_dense || n_slabs <= 0 || n_dense <= 0) return SRFRD_E_ARG;
+  if ((loss_part != nullptr) != (stats != nullptr)) return SRFRD_E_ARG;
+  const int grid = (int)((n_dense + 255) / 256);
+  hipLaunchKernelGGL(reduce_dense_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_slabs, n_slabs, n_dense,
+                     grad_dense, loss_part, B, stats);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_step_begin(uint32_t* state, double lr, double beta1, double beta2, void* stream) {
+  if (!state) return SRFRD_E_ARG;
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, beta1, beta2);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_adam_step(float* param, float* grad, float* m, float* v, int64_t n, int64_t i0, int64_t i1,
+                               int64_t n_zero, double beta1, double beta2, double eps, const uint32_t* state,
+                               const float* stats, void* stream) {
+  if (!param || !grad || !m || !v || !state || n <= 0 || i0 < 0 || i1 > n || i0 > i1 || (i0 & 3)) return SRFRD_E_ARG;
+  if (i0 == i1) return 0;
+  const int64_t nvec = ((i1 - i0) >> 2) + 1;
+  int64_t grid = (nvec + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(adam_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, i0, i1, n_zero,
+                     (float)beta1, (float)beta2, (float)eps, state, stats);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_loss_finalize(const float* stats, float* loss_out, void* stream) {
+  if (!stats || !loss_out) return SRFRD_E_ARG;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, loss_out);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,273 @@
+// Ranking-side kernels: user labels, candidate logits (predict), full-catalog top-k, HR@10 / NDCG@10 ranks.
+// Reference: SRFR_model.py:144-152 (+ :241-259, :532-540, :668-681), :546-570; utils.py:576-598.
+#include "srfrd_dev.h"
+
+namespace srfrd {
+
+// ---------------------------------------------------------------------------------------------
+// get_Labels / SRFRN predict label: one wave per sequence (integer-exact)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) user_labels_kernel(int kind, const int64_t* __restrict__ fake_ids, int B, int L,
+                                                         int64_t* __restrict__ labels) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int n1 = 0, n2 = 0;
+  for (int t = lane; t < L; t += 64) {
+    const int f = (int)fake_ids[(int64_t)b * L + t];
+    n1 += (f == 1);
+    n2 += (f == 2);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n1 += __shfl_xor(n1, o, 64);
+    n2 += __shfl_xor(n2, o, 64);
+  }
+  int lab;
+  if (kind == SRFRD_SRFU_B) lab = (n1 < n2) ? 1 : 2;
+  else if (kind == SRFRD_SRFU_F) lab = n1;
+  else if (kind == SRFRD_SRFU_R) {
+    const int tot = n1 + n2;
+    lab = tot == 0 ? 0 : (int)floorf(((float)n1 / (float)tot) * 10.0f);
+  } else lab = (n1 > n2) ? 2 : 1;
+  if (lane == 0) labels[b] = lab;
+}
+
+// ---------------------------------------------------------------------------------------------
+// predict: one wave per (user, candidate); lane = channel
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) predict_logits_kernel(srfrd_layout ly, const float* __restrict__ table,
+                                                            const float* __restrict__ dense, const float* __restrict__ hidden,
+                                                            int B, int L, const int64_t* __restrict__ cand, int n_cand,
+                                                            int64_t cand_stride, const int64_t* __restrict__ user_label,
+                                                            float* __restrict__ logits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= (int64_t)B * n_cand) return;
+  const int b = (int)(w / n_cand), i = (int)(w - (int64_t)b * n_cand);
+  const int dout = ly.d_out, di = ly.d_item;
+  const float h = lane < dout ? hidden[((int64_t)b * L + (L - 1)) * dout + lane] : 0.f;
+  const int64_t id = cand[(int64_t)b * cand_stride + i];
+  float e = 0.f;
+  if (lane < di) e = table[id * di + lane];
+  else if (ly.kind == SRFRD_SRFRN && lane < ly.D) e = dense[ly.off_side + (int)user_label[b] * ly.d_fake + (lane - di)];
+  const float s = wave_sum(h * e);
+  if (lane == 0) logits[w] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// full-catalog top-k.  Stage 1: a workgroup stages a chunk of kChunk item rows in LDS once, then for every
+// 16-user tile forms the 16 x kChunk logits on the fp32 matrix cores and selects each user's k best of the
+// chunk (value desc, item id asc).  Stage 2 merges the per-chunk candidates.  Logits never reach HBM.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChunk = 512;
+
+struct Cand {
+  float v;
+  int32_t i;
+};
+
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+// k rounds of (argmax, remove) over `n` scores in LDS by one wave; writes k candidates
+__device__ __forceinline__ void wave_select_topk(float* sc, const int* ids, int n, int k, Cand* out) {
+  const int lane = threadIdx.x & 63;
+  for (int r = 0; r < k; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7FFFFFFF, bp = -1;
+    for (int j = lane; j < n; j += 64) {
+      const float v = sc[j];
+      const int id = ids ? ids[j] : j;
+      if (v != -INFINITY && better(v, id, bv, bi)) { bv = v; bi = id; bp = j; }   // -inf marks removed / invalid
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      const int op = __shfl_xor(bp, o, 64);
+      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; bp = op; }
+    }
+    if (lane == 0) {
+      out[r].v = bv;
+      out[r].i = bp >= 0 ? bi : -1;
+      if (bp >= 0) sc[bp] = -INFINITY;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ void __launch_bounds__(256) topk_stage1_kernel(srfrd_layout ly, const float* __restrict__ table,
+                                                         const float* __restrict__ dense, const float* __restrict__ hidden,
+                                                         int B, int L, int64_t item_lo, int64_t item_hi, int exclude_pad,
+                                                         const int64_t* __restrict__ user_label, int k, int n_chunks,
+                                                         Cand* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int di = ly.d_item, dout = ly.d_out, D = ly.D;
+  const bool srfrn = ly.kind == SRFRD_SRFRN;
+  const int DKi = (di + 3) & ~3, DSi = DKi + 2;
+  const int SLD = kChunk + 2;
+  float* sE = smem;                       // [kChunk][DSi] item rows of this chunk
+  float* sH = sE + kChunk * DSi;          // [16][DSi]     last hidden state of 16 users (item part)
+  float* sS = sH + 16 * DSi;              // [16][SLD]     logits
+  float* sF = sS + 16 * SLD;              // [16]          SRFRN: <h[di:], fake_embed[label]> per user
+  const int chunk = blockIdx.x;
+  const int64_t i0 = item_lo + (int64_t)chunk * kChunk;
+  const int n_here = (int)((item_hi - i0) < kChunk ? (item_hi - i0) : kChunk);
+  for (int idx = tid; idx < kChunk * DSi; idx += blockDim.x) {
+    const int r = idx / DSi, c = idx - r * DSi;
+    sE[idx] = (r < n_here && c < di) ? table[(i0 + r) * di + c] : 0.f;
+  }
+  for (int u0 = 0; u0 < B; u0 += 16) {
+    __syncthreads();
+    for (int idx = tid; idx < 16 * DSi; idx += blockDim.x) {
+      const int r = idx / DSi, c = idx - r * DSi;
+      sH[idx] = (u0 + r < B && c < di) ? hidden[((int64_t)(u0 + r) * L + (L - 1)) * dout + c] : 0.f;
+    }
+    if (srfrn && tid < 16) {
+      float s = 0.f;
+      if (u0 + tid < B) {
+        const int lab = (int)user_label[u0 + tid];
+        for (int c = di; c < D; ++c) s += hidden[((int64_t)(u0 + tid) * L + (L - 1)) * dout + c] * dense[ly.off_side + lab * ly.d_fake + (c - di)];
+      }
+      sF[tid] = s;
+    }
+    __syncthreads();
+    gemm_tiles<0>(1, kChunk / 16, DKi, Mat{sH, DSi}, MatT{sE, DSi}, [&](int r, int c, float v) {
+      if (srfrn) v += sF[r];
+      const bool ok = c < n_here && !(exclude_pad && i0 + c == 0);
+      sS[r * SLD + c] = ok ? v : -INFINITY;
+    });
+    __syncthreads();
+    for (int r = wave; r < 16; r += nw)
+      if (u0 + r < B) {
+        Cand* out = ws + ((int64_t)(u0 + r) * n_chunks + chunk) * k;
+        wave_select_topk(sS + r * SLD, nullptr, kChunk, k, out);
+        if (lane == 0)
+          for (int q = 0; q < k; ++q)
+            if (out[q].i >= 0) out[q].i += (int32_t)i0;       // chunk-local position -> item id
+      }
+  }
+}
+
+__global__ void __launch_bounds__(256) topk_stage2_kernel(const Cand* __restrict__ ws, int B, int k, int n_chunks,
+                                                         int64_t* __restrict__ topk_idx, float* __restrict__ topk_val,
+                                                         Cand* __restrict__ scratch_unused) {
+  // one wave per user: k rounds of argmax over its n_chunks*k candidates (kept in global; -inf marks removed)
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  Cand* c = const_cast<Cand*>(ws) + (int64_t)b * n_chunks * k;
+  const int n = n_chunks * k;
+  for (int r = 0; r < k; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7FFFFFFF, bp = -1;
+    for (int j = lane; j < n; j += 64) {
+      const float v = c[j].v;
+      const int id = c[j].i;
+      if (id >= 0 && v != -INFINITY && better(v, id, bv, bi)) { bv = v; bi = id; bp = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      const int op = __shfl_xor(bp, o, 64);
+      if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; bp = op; }
+    }
+    if (lane == 0) {
+      topk_idx[(int64_t)b * k + r] = bp >= 0 ? bi : -1;
+      topk_val[(int64_t)b * k + r] = bv;
+      if (bp >= 0) c[bp].i = -1;
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rank of candidate 0 (strictly-greater count) + HR@10 / NDCG@10 accumulation (fp64, as the host loop does)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) eval_rank_kernel(const float* __restrict__ logits, int B, int n_cand,
+                                                       int32_t* __restrict__ rank, double* __restrict__ metric_acc) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* row = logits + (int64_t)b * n_cand;
+  const float x0 = row[0];
+  int cnt = 0;
+  for (int j = 1 + lane; j < n_cand; j += 64) cnt += row[j] > x0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if (lane == 0) {
+    if (rank) rank[b] = cnt;
+    if (metric_acc) {
+      if (cnt < 10) {
+        atomicAdd(&metric_acc[0], 1.0 / log2((double)cnt + 2.0));
+        atomicAdd(&metric_acc[1], 1.0);
+      }
+      atomicAdd(&metric_acc[2], 1.0);
+    }
+  }
+}
+
+}  // namespace srfrd
+
+using namespace srfrd;
+
+extern "C" int srfrd_user_labels(int kind, const int64_t* fake_ids, int B, int L, int64_t* labels, void* stream) {
+  if (!fake_ids || !labels || B <= 0 || L <= 0) return SRFRD_E_ARG;
+  if (!(kind == SRFRD_SRFU_B || kind == SRFRD_SRFU_F || kind == SRFRD_SRFU_R || kind == SRFRD_SRFRN)) return SRFRD_E_ARG;
+  hipLaunchKernelGGL(user_labels_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, kind, fake_ids, B, L, labels);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_predict_logits(const srfrd_layout* lay, const float* item_table, const float* dense,
+                                    const float* hidden, int B, int L, const int64_t* cand, int n_cand, int64_t cand_stride,
+                                    const int64_t* user_label, float* logits, void* stream) {
+  if (!lay || !item_table || !dense || !hidden || !cand || !logits || B <= 0 || L <= 0 || n_cand <= 0) return SRFRD_E_ARG;
+  if (lay->D > SRFRD_MAX_D) return SRFRD_E_UNSUPPORTED;
+  if (lay->kind == SRFRD_SRFRN && !user_label) return SRFRD_E_ARG;
+  const int64_t waves = (int64_t)B * n_cand;
+  hipLaunchKernelGGL(predict_logits_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *lay,
+                     item_table, dense, hidden, B, L, cand, n_cand, cand_stride, user_label, logits);
+  return (int)hipGetLastError();
+}
+
+extern "C" int64_t srfrd_topk_workspace_bytes(int B, int k, int64_t n_rows) {
+  if (B <= 0 || k <= 0 || n_rows <= 0) return 0;
+  const int64_t n_chunks = (n_rows + kChunk - 1) / kChunk;
+  return (int64_t)B * n_chunks * k * (int64_t)sizeof(Cand);
+}
+
+extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const float* item_table, const float* dense,
+                                 const float* hidden, int B, int L, int64_t item_lo, int64_t item_hi, int exclude_pad,
+                                 const int64_t* user_label, int k, int64_t* topk_idx, float* topk_val, void* workspace,
+                                 void* stream) {
+  if (!lay || !item_table || !dense || !hidden || !topk_idx || !topk_val || !workspace) return SRFRD_E_ARG;
+  if (B <= 0 || L <= 0 || k <= 0 || k > 64 || item_lo < 0 || item_hi <= item_lo || item_hi > (int64_t)lay->n_items + 1) return SRFRD_E_ARG;
+  if (lay->D > SRFRD_MAX_D) return SRFRD_E_UNSUPPORTED;
+  if (lay->kind == SRFRD_SRFRN && !user_label) return SRFRD_E_ARG;
+  const int n_chunks = (int)((item_hi - item_lo + kChunk - 1) / kChunk);
+  const int DSi = ((lay->d_item + 3) & ~3) + 2;
+  const size_t lds = ((size_t)kChunk * DSi + 16 * DSi + 16 * (kChunk + 2) + 16 + kSlack) * sizeof(float);
+  if (lds > (size_t)kLdsLimit) return SRFRD_E_UNSUPPORTED;
+  static size_t s_attr = 0;
+  if (lds > s_attr) {
+    if (hipFuncSetAttribute((const void*)topk_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SRFRD_E_DEVICE;
+    s_attr = lds;
+  }
+  hipLaunchKernelGGL(topk_stage1_kernel, dim3(n_chunks), dim3(256), lds, (hipStream_t)stream, *lay, item_table, dense,
+                     hidden, B, L, item_lo, item_hi, exclude_pad, user_label, k, n_chunks, (Cand*)workspace);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(topk_stage2_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Cand*)workspace, B, k,
+                     n_chunks, topk_idx, topk_val, (Cand*)nullptr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_eval_rank(const float* logits, int B, int n_cand, int32_t* rank, double* metric_acc, void* stream) {
+  if (!logits || B <= 0 || n_cand <= 0) return SRFRD_E_ARG;
+  hipLaunchKernelGGL(eval_rank_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, B, n_cand, rank, metric_acc);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,460 @@
+"""Drop-in ``nn.Module`` surface of the reference model zoo, backed by the HIP kernels.
+
+Same class names, positional constructor signatures, ``forward`` / ``predict`` signatures, attribute tree and
+``state_dict`` keys as the reference (SRFR_model.py:53 SRFR, :154 SRFRN, :429 SRFU, :543/:553/:562 SRFU_B/F/R,
+:572 SASRec).  The stock ``nn.Embedding`` / ``nn.LayerNorm`` / ``nn.MultiheadAttention`` /
+``nn.Conv1d`` objects are kept ONLY as parameter containers (created in the reference's construction order, so a
+given ``torch.manual_seed`` yields the same initial weights); none of their ``forward`` methods is ever called.
+All arithmetic runs in ``libsrfrd_hip.so``; on a non-CUDA device or without the library, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ids(t, device, shape=None):
+    if t is None:
+        return None
+    t = torch.as_tensor(t)
+    if t.device != device or t.dtype != torch.int64 or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.int64).contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"id tensor has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+class PointWiseFeedForward(nn.Module):
+    """Parameter container for reference SRFR_model.py:36-51 (conv1 / conv2 with kernel_size=1)."""
+
+    def __init__(self, in_channel, out_channel, pwff_dropout_rate):
+        super().__init__()
+        self.conv1 = nn.Conv1d(in_channel, out_channel, kernel_size=1)
+        self.dropout1 = nn.Dropout(p=pwff_dropout_rate)
+        self.relu = nn.ReLU()
+        self.conv2 = nn.Conv1d(out_channel, out_channel, kernel_size=1)
+        self.dropout2 = nn.Dropout(p=pwff_dropout_rate)
+
+
+class SRFR_Embedding(nn.Module):
+    """Parameter container for reference SRFR_model.py:6-15."""
+
+    def __init__(self, item_number, item_embedding_size, fake_embedding_size, dropout_rate, maxlen, device):
+        super().__init__()
+        self.item_embed = nn.Embedding(item_number + 1, item_embedding_size, padding_idx=0)
+        self.fake_embed = nn.Embedding(3, fake_embedding_size, padding_idx=0)   # 0 padding, 1 fake, 2 real
+        self.pos_embed = nn.Embedding(maxlen, item_embedding_size)
+        self.total_hiden_size = item_embedding_size + fake_embedding_size
+        self.dropout = nn.Dropout(p=dropout_rate)
+        self.device = device
+
+
+class SRFU_Embedding(nn.Module):
+    """Parameter container for reference SRFR_model.py:399-409."""
+
+    def __init__(self, item_number, item_embedding_size, number_of_labels, dropout_rate, maxlen, device):
+        super().__init__()
+        self.item_embed = nn.Embedding(item_number + 1, item_embedding_size, padding_idx=0)
+        self.user_label_embed = nn.Embedding(number_of_labels, item_embedding_size)
+        self.pos_embed = nn.Embedding(maxlen, item_embedding_size)
+        self.dropout = nn.Dropout(p=dropout_rate)
+        self.device = device
+        self.item_embedding_size = item_embedding_size
+        self.number_of_labels = number_of_labels
+        self.maxlen = maxlen
+
+    def get_user_label_embed(self):
+        return self.user_label_embed
+
+
+class _EncoderFn(torch.autograd.Function):
+    """autograd bridge: forward = srfrd_encoder_fwd, backward = srfrd_encoder_bwd + srfrd_reduce_dense."""
+
+    @staticmethod
+    def forward(ctx, model, ids, dropout_p, seed, *params):
+        inp, fk, pos, pfk, neg, nfk = ids
+        out = model._launch_fwd(inp, fk, pos, pfk, neg, nfk, dropout_p, seed, save=True)
+        ctx.model, ctx.ids, ctx.dropout_p, ctx.seed = model, ids, dropout_p, seed
+        ctx.saved = out
+        hidden, pl, nl = out["hidden"], out["pos_logits"], out["neg_logits"]
+        empty = hidden.new_empty(0)
+        return hidden, (pl if pl is not None else empty), (nl if nl is not None else empty)
+
+    @staticmethod
+    def backward(ctx, d_hidden, d_pl, d_nl):
+        model, out = ctx.model, ctx.saved
+        inp, fk, pos, pfk, neg, nfk = ctx.ids
+        if out["pos_logits"] is None:
+            d_pl = None
+        if out["neg_logits"] is None:
+            d_nl = None
+        gflat = model._launch_bwd(inp, fk, pos, pfk, neg, nfk, ctx.dropout_p, ctx.seed, out,
+                                  None if d_hidden is None else d_hidden.contiguous(),
+                                  None if d_pl is None else d_pl.contiguous(),
+                                  None if d_nl is None else d_nl.contiguous())
+        grads = tuple(gflat[off:off + p.numel()].view(p.shape) for p, off in model._slots)
+        return (None, None, None, None) + grads
+
+
+class _SRFRDBase(nn.Module):
+    """Shared machinery: flat parameter storage, kernel launches, predict."""
+
+    _kind = None
+
+    # ---- construction helpers (same order as the reference constructors)
+    def _build_blocks(self, hidden, num_blocks, num_heads, dropout_rate):
+        for _ in range(num_blocks):
+            self.attention_layernorms.append(nn.LayerNorm(hidden, eps=1e-8))
+            self.attention_layers.append(nn.MultiheadAttention(hidden, num_heads, dropout_rate))
+            self.forward_layernorms.append(nn.LayerNorm(hidden, eps=1e-8))
+            self.forward_layers.append(PointWiseFeedForward(hidden, hidden, dropout_rate))
+
+    def _init_lists(self):
+        self.attention_layernorms = nn.ModuleList()
+        self.attention_layers = nn.ModuleList()
+        self.forward_layernorms = nn.ModuleList()
+        self.forward_layers = nn.ModuleList()
+
+    def _finish(self, item_number, max_len, d_item, d_fake, n_labels, num_blocks, num_heads, dropout_rate):
+        self._cfg = dict(kind=self._kind, n_items=item_number, max_len=max_len, d_item=d_item, d_fake=d_fake,
+                         n_labels=n_labels, n_blocks=num_blocks, n_heads=num_heads)
+        self.dropout_rate = float(dropout_rate)
+        self._lay = None
+        self._flat = None
+        self._slots = None
+
+    # ---- layout / flat storage
+    @property
+    def layout(self):
+        if self._lay is None:
+            self._lay = _lib.make_layout(**self._cfg)
+        return self._lay
+
+    def _item_param(self):
+        raise NotImplementedError
+
+    def _dense_params(self):
+        """[(parameter, dense offset)] in the canonical order of include/srfrd_hip.h."""
+        raise NotImplementedError
+
+    def _block_params(self, lay):
+        out = []
+        for i in range(lay.n_blocks):
+            o, mha, ff = lay.blk[i], self.attention_layers[i], self.forward_layers[i]
+            out += [(self.attention_layernorms[i].weight, o.ln1_w), (self.attention_layernorms[i].bias, o.ln1_b),
+                    (mha.in_proj_weight, o.in_w), (mha.in_proj_bias, o.in_b),
+                    (mha.out_proj.weight, o.out_w), (mha.out_proj.bias, o.out_b),
+                    (self.forward_layernorms[i].weight, o.ln2_w), (self.forward_layernorms[i].bias, o.ln2_b),
+                    (ff.conv1.weight, o.c1_w), (ff.conv1.bias, o.c1_b), (ff.conv2.weight, o.c2_w), (ff.conv2.bias, o.c2_b)]
+        return out
+
+    @property
+    def n_table_pad(self):
+        return (self.layout.n_table + 3) // 4 * 4
+
+    @property
+    def n_flat(self):
+        return (self.n_table_pad + self.layout.n_dense + 3) // 4 * 4
+
+    def flat_parameters(self):
+        """The single fp32 vector [item table | pad | dense parameters] every nn.Parameter is a view of."""
+        self._ensure_flat()
+        return self._flat
+
+    def _ensure_flat(self):
+        lay = self.layout
+        table = self._item_param()
+        dev = table.device
+        if dev.type != "cuda":
+            raise RuntimeError("srfrd_amd modules compute only on a ROCm GPU (device 'cuda'); move the model with "
+                               ".to('cuda'). There is no CPU fallback.")
+        if lay.D > _lib.MAX_D or lay.n_heads != 1:
+            raise NotImplementedError("the fused MI355X kernels cover hidden width <= 64 and num_heads == 1 "
+                                      f"(got width {lay.D}, heads {lay.n_heads})")
+        slots = [(table, 0)] + [(p, self.n_table_pad + off) for p, off in self._dense_params()]
+        flat = self._flat
+        if flat is not None and flat.device == dev:
+            base = flat.data_ptr()
+            if all(p.data_ptr() == base + 4 * off and p.dtype == torch.float32 for p, off in slots):
+                self._slots = slots
+                return
+        flat = torch.zeros(self.n_flat, device=dev, dtype=torch.float32)
+        covered = 0
+        for p, off in slots:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1).to(device=dev, dtype=torch.float32))
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = None
+            covered += n
+        assert covered == lay.n_table + lay.n_dense, "parameter list does not match the dense layout"
+        self._flat, self._slots = flat, slots
+
+    # ---- launches
+    def _launch_fwd(self, inp, fk, pos, pfk, neg, nfk, dropout_p, seed, save, seq0=0, dbg=None, dbg_seq=0):
+        lay, flat = self.layout, self._flat
+        B, L = inp.shape
+        dev = inp.device
+        hidden = torch.empty(B, L, lay.d_out, device=dev, dtype=torch.float32)
+        pl = torch.empty(B, L, device=dev, dtype=torch.float32) if pos is not None else None
+        nl = torch.empty(B, L, device=dev, dtype=torch.float32) if neg is not None else None
+        sx = torch.empty(lay.n_blocks + 1, B, L, lay.D, device=dev, dtype=torch.float32) if save else None
+        sh = torch.empty(lay.n_blocks, B, L, lay.D, device=dev, dtype=torch.float32) if save else None
+        check(_lib.lib().srfrd_encoder_fwd(
+            C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad),
+            ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
+            None, int(seq0), ptr(hidden), ptr(pl), ptr(nl), ptr(sx), ptr(sh), None, ptr(dbg), int(dbg_seq), _stream()),
+            "srfrd_encoder_fwd")
+        return {"hidden": hidden, "pos_logits": pl, "neg_logits": nl, "save_x": sx, "save_h1": sh}
+
+    def _launch_bwd(self, inp, fk, pos, pfk, neg, nfk, dropout_p, seed, out, d_hidden, d_pl, d_nl, seq0=0,
+                    dbg=None, dbg_seq=0):
+        lay, flat = self.layout, self._flat
+        B, L = inp.shape
+        dev = inp.device
+        gflat = torch.zeros(self.n_flat, device=dev, dtype=torch.float32)
+        n_slabs = _lib.lib().srfrd_bwd_grid(B)
+        slabs = torch.empty(n_slabs, lay.n_dense, device=dev, dtype=torch.float32)
+        check(_lib.lib().srfrd_encoder_bwd(
+            C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad),
+            ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
+            None, int(seq0), ptr(out["hidden"]), ptr(out["pos_logits"]), ptr(out["neg_logits"]), ptr(out["save_x"]),
+            ptr(out["save_h1"]), ptr(d_hidden), ptr(d_pl), ptr(d_nl), 0, ptr(gflat), ptr(slabs), ptr(dbg), int(dbg_seq),
+            _stream()), "srfrd_encoder_bwd")
+        check(_lib.lib().srfrd_reduce_dense(ptr(slabs), n_slabs, lay.n_dense,
+                                            C.c_void_p(gflat.data_ptr() + 4 * self.n_table_pad), None, B, None, _stream()),
+              "srfrd_reduce_dense")
+        return gflat
+
+    def _prep(self, input_ids, fake_ids, positive_ids, positive_fake_ids, negative_ids, negative_fake_ids):
+        self._ensure_flat()
+        dev = self._flat.device
+        inp = _ids(input_ids, dev)
+        if inp.dim() != 2:
+            raise ValueError("input_ids must be (batch, seq_len)")
+        if inp.shape[1] > self.layout.max_len:
+            raise IndexError(f"sequence length {inp.shape[1]} exceeds max_len {self.layout.max_len}")
+        shp = inp.shape
+        fk = _ids(fake_ids, dev, shp)
+        pos, neg = _ids(positive_ids, dev, shp), _ids(negative_ids, dev, shp)
+        pfk = _ids(positive_fake_ids, dev, shp) if self._kind == "SRFRN" and pos is not None else None
+        nfk = _ids(negative_fake_ids, dev, shp) if self._kind == "SRFRN" and neg is not None else None
+        if self._kind.startswith("SRFU") and fk is None:
+            raise ValueError("SRFU models need fake_ids to derive the user label")
+        return inp, fk, pos, pfk, neg, nfk
+
+    def forward(self, user_ids, input_ids, fake_ids, positive_ids=None, positive_fake_ids=None, negative_ids=None,
+                negative_fake_ids=None):
+        """-> (hidden_state (B,L,d_out), pos_logits (B,L) | None, neg_logits (B,L) | None); ``user_ids`` is unused,
+        exactly as in the reference (SRFR_model.py:92, :192, :473, :651)."""
+        ids = self._prep(input_ids, fake_ids, positive_ids, positive_fake_ids, negative_ids, negative_fake_ids)
+        p = self.dropout_rate if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
+        if torch.is_grad_enabled() and any(q.requires_grad for q, _ in self._slots):
+            hidden, pl, nl = _EncoderFn.apply(self, ids, p, seed, *[q for q, _ in self._slots])
+            return hidden, (pl if ids[2] is not None else None), (nl if ids[4] is not None else None)
+        out = self._launch_fwd(*ids, p, seed, save=False)
+        return out["hidden"], out["pos_logits"], out["neg_logits"]
+
+    def user_labels(self, fake_ids):
+        """get_Labels (SRFU_*) / the predict-time label (SRFRN) as an int64 (B,) tensor, computed on device."""
+        self._ensure_flat()
+        fk = _ids(fake_ids, self._flat.device)
+        lab = torch.empty(fk.shape[0], device=fk.device, dtype=torch.int64)
+        kind = _lib.KINDS[self._kind] if self._kind != "SRFR" else _lib.KINDS["SRFRN"]
+        check(_lib.lib().srfrd_user_labels(kind, ptr(fk), fk.shape[0], fk.shape[1], ptr(lab), _stream()),
+              "srfrd_user_labels")
+        return lab
+
+    def predict(self, user_ids, input_ids, fake_ids, label):
+        """reference predict(): logits of the candidate items ``label`` against the last position's state.
+        ``label`` is (I_c,) shared by the batch (reference utils.py:589) or (B, I_c) per user (batched eval);
+        returns (I_c,) for a single sequence, else (B, I_c) - the reference's ``.squeeze()`` behaviour."""
+        with torch.no_grad():
+            ids = self._prep(input_ids, fake_ids, None, None, None, None)
+            out = self._launch_fwd(*ids, 0.0, 0, save=False)
+        logits = self.candidate_logits(out["hidden"], ids[1], label)
+        return logits.squeeze()
+
+    def candidate_logits(self, hidden, fake_ids, cand):
+        lay = self.layout
+        dev = hidden.device
+        B, L = hidden.shape[0], hidden.shape[1]
+        cand = _ids(cand, dev)
+        stride = 0 if cand.dim() == 1 else cand.shape[1]
+        n_cand = cand.shape[-1]
+        if cand.dim() == 2 and cand.shape[0] != B:
+            raise ValueError("per-user candidates must be (B, I_c)")
+        ulab = self.user_labels(fake_ids) if self._kind == "SRFRN" else None
+        logits = torch.empty(B, n_cand, device=dev, dtype=torch.float32)
+        check(_lib.lib().srfrd_predict_logits(
+            C.byref(lay), ptr(self._flat), C.c_void_p(self._flat.data_ptr() + 4 * self.n_table_pad), ptr(hidden), B, L,
+            ptr(cand), n_cand, stride, ptr(ulab), ptr(logits), _stream()), "srfrd_predict_logits")
+        return logits
+
+    def topk(self, user_ids, input_ids, fake_ids, k=10, exclude_pad=True, item_range=None):
+        """Full-catalog ranking: (indices int64 (B,k), scores (B,k)); the (B, I) logits never reach HBM."""
+        with torch.no_grad():
+            ids = self._prep(input_ids, fake_ids, None, None, None, None)
+            out = self._launch_fwd(*ids, 0.0, 0, save=False)
+        lay = self.layout
+        hidden = out["hidden"]
+        B, L = hidden.shape[0], hidden.shape[1]
+        lo, hi = item_range if item_range is not None else (0, lay.n_items + 1)
+        ulab = self.user_labels(ids[1]) if self._kind == "SRFRN" else None
+        ws = torch.empty(max(_lib.lib().srfrd_topk_workspace_bytes(B, k, hi - lo), 8), device=hidden.device, dtype=torch.uint8)
+        idx = torch.empty(B, k, device=hidden.device, dtype=torch.int64)
+        val = torch.empty(B, k, device=hidden.device, dtype=torch.float32)
+        check(_lib.lib().srfrd_logits_topk(
+            C.byref(lay), ptr(self._flat), C.c_void_p(self._flat.data_ptr() + 4 * self.n_table_pad), ptr(hidden), B, L,
+            lo, hi, 1 if exclude_pad else 0, ptr(ulab), k, ptr(idx), ptr(val), ptr(ws), _stream()), "srfrd_logits_topk")
+        return idx, val
+
+
+class SRFR(_SRFRDBase):
+    """reference SRFR_model.py:53-152: [item || fake] input channel, last_conv D -> d_item, item-only targets."""
+    _kind = "SRFR"
+
+    def __init__(self, item_number, max_len=20, item_embedding_size=50, fake_embedding_size=10, dropout_rate=0.5,
+                 num_blocks=2, num_heads=1, device="cpu"):
+        super().__init__()
+        self.device = device
+        self.total_hidden_size = item_embedding_size + fake_embedding_size
+        self.embedding_layer = SRFR_Embedding(item_number, item_embedding_size, fake_embedding_size, dropout_rate,
+                                              max_len, device)
+        self._init_lists()
+        self.last_conv = nn.Conv1d(self.total_hidden_size, item_embedding_size, kernel_size=1)
+        self.last_layernorm = nn.LayerNorm(item_embedding_size, eps=1e-8)
+        self._build_blocks(self.total_hidden_size, num_blocks, num_heads, dropout_rate)
+        self._finish(item_number, max_len, item_embedding_size, fake_embedding_size, 0, num_blocks, num_heads, dropout_rate)
+
+    def _item_param(self):
+        return self.embedding_layer.item_embed.weight
+
+    def _dense_params(self):
+        lay = self.layout
+        return ([(self.embedding_layer.pos_embed.weight, lay.off_pos), (self.embedding_layer.fake_embed.weight, lay.off_side)]
+                + self._block_params(lay)
+                + [(self.last_conv.weight, lay.off_lc_w), (self.last_conv.bias, lay.off_lc_b),
+                   (self.last_layernorm.weight, lay.off_ll_w), (self.last_layernorm.bias, lay.off_ll_b)])
+
+
+class SRFRN(_SRFRDBase):
+    """reference SRFR_model.py:154-259: [item || fake] channel in and out; targets carry their fake embedding."""
+    _kind = "SRFRN"
+
+    def __init__(self, item_number, max_len=20, item_embedding_size=50, fake_embedding_size=10, dropout_rate=0.5,
+                 num_blocks=2, num_heads=1, device="cpu"):
+        super().__init__()
+        self.device = device
+        self.total_hidden_size = item_embedding_size + fake_embedding_size
+        self.embedding_layer = SRFR_Embedding(item_number, item_embedding_size, fake_embedding_size, dropout_rate,
+                                              max_len, device)
+        self._init_lists()
+        self.last_layernorm = nn.LayerNorm(self.total_hidden_size, eps=1e-8)
+        self._build_blocks(self.total_hidden_size, num_blocks, num_heads, dropout_rate)
+        self._finish(item_number, max_len, item_embedding_size, fake_embedding_size, 0, num_blocks, num_heads, dropout_rate)
+
+    def _item_param(self):
+        return self.embedding_layer.item_embed.weight
+
+    def _dense_params(self):
+        lay = self.layout
+        return ([(self.embedding_layer.pos_embed.weight, lay.off_pos), (self.embedding_layer.fake_embed.weight, lay.off_side)]
+                + self._block_params(lay)
+                + [(self.last_layernorm.weight, lay.off_ll_w), (self.last_layernorm.bias, lay.off_ll_b)])
+
+
+class SRFU(_SRFRDBase):
+    """reference SRFR_model.py:429-540: per-user label embedding added to every position."""
+    _kind = None
+
+    def __init__(self, item_number, max_len=20, item_embedding_size=50, number_of_labels=2, dropout_rate=0.5,
+                 num_blocks=2, num_heads=1, device="cpu"):
+        super().__init__()
+        self.device = device
+        self.maxlen = max_len
+        self.embedding_layer = SRFU_Embedding(item_number, item_embedding_size, number_of_labels, dropout_rate, max_len,
+                                              device)
+        self._init_lists()
+        self.last_layernorm = nn.LayerNorm(item_embedding_size, eps=1e-8)
+        self._build_blocks(item_embedding_size, num_blocks, num_heads, dropout_rate)
+        self._finish(item_number, max_len, item_embedding_size, 0, number_of_labels, num_blocks, num_heads, dropout_rate)
+
+    def get_Labels(self, fake_ids):
+        if self._kind is None:      # the reference base class raises too (SRFR_model.py:467-471)
+            raise TypeError("not implemented result")
+        return self.user_labels(fake_ids)
+
+    def _ensure_flat(self):
+        if self._kind is None:
+            raise TypeError("not implemented result")
+        super()._ensure_flat()
+
+    def _item_param(self):
+        return self.embedding_layer.item_embed.weight
+
+    def _dense_params(self):
+        lay = self.layout
+        return ([(self.embedding_layer.pos_embed.weight, lay.off_pos),
+                 (self.embedding_layer.user_label_embed.weight, lay.off_side)]
+                + self._block_params(lay)
+                + [(self.last_layernorm.weight, lay.off_ll_w), (self.last_layernorm.bias, lay.off_ll_b)])
+
+
+class SRFU_B(SRFU):
+    """binary user label, reference SRFR_model.py:543-551 (more fake -> 2, more real -> 1, tie -> 2)."""
+    _kind = "SRFU_B"
+
+
+class SRFU_F(SRFU):
+    """frequency user label = number of fake reviews, reference SRFR_model.py:553-560."""
+    _kind = "SRFU_F"
+
+
+class SRFU_R(SRFU):
+    """ratio user label = floor(10 * fake / (fake + real)), reference SRFR_model.py:562-570."""
+    _kind = "SRFU_R"
+
+
+class SASRec(_SRFRDBase):
+    """reference SRFR_model.py:572-681."""
+    _kind = "SASRec"
+
+    def __init__(self, item_number, maxlen=20, hidden_units=50, dropout_rate=0.5, num_blocks=2, num_heads=1, device="cpu"):
+        super().__init__()
+        self.item_num = item_number
+        self.dev = device
+        self.item_emb = nn.Embedding(self.item_num + 1, hidden_units, padding_idx=0)
+        self.pos_emb = nn.Embedding(maxlen, hidden_units)
+        self.emb_dropout = nn.Dropout(p=dropout_rate)
+        self._init_lists()
+        self.last_layernorm = nn.LayerNorm(hidden_units, eps=1e-8)
+        self._build_blocks(hidden_units, num_blocks, num_heads, dropout_rate)
+        self._finish(item_number, maxlen, hidden_units, 0, 0, num_blocks, num_heads, dropout_rate)
+
+    def _item_param(self):
+        return self.item_emb.weight
+
+    def _dense_params(self):
+        lay = self.layout
+        return ([(self.pos_emb.weight, lay.off_pos)] + self._block_params(lay)
+                + [(self.last_layernorm.weight, lay.off_ll_w), (self.last_layernorm.bias, lay.off_ll_b)])
+
+    def log2feats(self, log_seqs):
+        return self.forward(None, log_seqs, None)[0]
+
+    def forward(self, user_ids, input_ids, fake_ids, positive_ids=None, positive_fake_ids=None, negative_ids=None,
+                negative_fake_ids=None):
+        return super().forward(user_ids, input_ids, None, positive_ids, None, negative_ids, None)
+
+    def predict(self, user_ids, log_seqs, fake_ids, item_indices):
+        return super().predict(user_ids, log_seqs, None, item_indices)
