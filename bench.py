@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py -- sequences/sec of the fused SRFRD train step (reference trainer.py:27-41) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], "C2"): SASRec (discriminator off), 50 000 items, seq_len 50, batch 512 per GPU,
+hidden 50, 2 blocks, 1 head, dropout 0.5, Adam(1e-3, betas=(0.9, 0.98)), fp32 arithmetic, synthetic ids already in HBM.
+One step = forward + masked BCE + backward + dense Adam (+ gradient all-reduce over RCCL when N > 1); weak scaling.
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and, at N = 1, `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C2 = dict(kind="SASRec", n_items=50_000, seq_len=50, batch=512, hidden=50, blocks=2, heads=1, dropout=0.5)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (matrix) dense
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
+
+
+def algorithmic_flops_per_token(L, D, d_item, nb):
+    """forward flops per token = nb (12 D^2 + 4 L D) + 2 D d_i + 4 d_i."""
+    return nb * (12 * D * D + 4 * L * D) + 2 * D * d_item + 4 * d_item
+
+
+def algorithmic_bytes_per_step(I, L, B, D, d_item, nb, p_dense):
+    """SURVEY.md 8(d) `Algorithmic bytes per train step per GPU`, fp32 gathers (s_e = 4)."""
+    T = B * L
+    ids = 6 * T * 8 + B * 8
+    gather_fwd = 3 * T * d_item * 4
+    outputs = T * D * 4 + 2 * T * 4
+    regather_bwd = 3 * T * d_item * 4
+    grad_scatter = 2 * 3 * T * d_item * 4
+    grad_zero = (I + 1) * d_item * 4
+    adam_table = 7 * (I + 1) * d_item * 4
+    adam_dense = 7 * p_dense * 4
+    return ids + gather_fwd + outputs + regather_bwd + grad_scatter + grad_zero + adam_table + adam_dense
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity, capped by the cgroup CPU quota (a one-GPU box exposes
+    every host core but grants a 16-CPU share; oversubscribing OpenMP there stalls for minutes)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                quota = int(q) / int(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota)))
+    return max(1, min(n, int(os.environ.get("SRFRD_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """The oracle's restated trainer.py:27-41 step (torch CPU ops, dropout on) timed on this host's cores."""
+    from oracle import srfrd_oracle as O
+    import srfrd_amd
+    n_thr = host_cores()
+    torch.set_num_threads(n_thr)
+    log(f"cpu_baseline: {n_thr} threads")
+    ocfg = O.Cfg(cfg["kind"], cfg["n_items"], cfg["seq_len"], cfg["hidden"], num_blocks=cfg["blocks"],
+                 num_heads=cfg["heads"], dropout=cfg["dropout"])
+    torch.manual_seed(0)
+    m = srfrd_amd.SASRec(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["dropout"], cfg["blocks"], cfg["heads"], "cpu")
+    for _, p in m.named_parameters():
+        if p.dim() >= 2:
+            torch.nn.init.xavier_normal_(p.data)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    stepper = O.TorchStep(ocfg, sd)
+    batch = srfrd_amd.synthetic_batch(cfg["n_items"], cfg["seq_len"], cfg["batch"], seed=1, index=0, device="cpu")[1:]
+    for _ in range(2):
+        stepper.step(batch)
+    log("cpu_baseline: warm")
+    n, t0 = 0, time.perf_counter()
+    while True:
+        stepper.step(batch)
+        n += 1
+        el = time.perf_counter() - t0
+        if (n >= 10 and el > budget_s) or n >= 200 or el > 3 * budget_s:
+            break
+    log(f"cpu_baseline: {n} steps in {el:.1f} s")
+    return {"value": cfg["batch"] * n / el, "unit": "sequences/s", "cores": n_thr, "kind": "port",
+            "sample": f"{n} train steps of the same C2 batch shape (B={cfg['batch']}, L={cfg['seq_len']}, "
+                      f"I={cfg['n_items']}), {el:.1f} s, torch CPU fp32, dropout 0.5"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import srfrd_amd
+    cfg = C2
+    torch.manual_seed(0)                      # identical init on every rank (replicated parameters)
+    model = srfrd_amd.SASRec(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
+    for _, p in model.named_parameters():     # reference trainer.py:364-369
+        if p.dim() >= 2:
+            torch.nn.init.xavier_normal_(p.data)
+    model = model.to(dev).train()
+    B, L = cfg["batch"], cfg["seq_len"]
+    tr = srfrd_amd.FusedTrainer(model, B, L, lr=1e-3, betas=(0.9, 0.98), seed=42, use_graph=not args.no_graph)
+    batches = [srfrd_amd.synthetic_batch(cfg["n_items"], L, B, seed=1, index=i, rank=rank, device=dev, packed=True)[1]
+               for i in range(8)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("model + batches ready")
+    for i in range(args.warmup):
+        tr.step_packed(batches[i % 8])
+    barrier()
+    log("warm-up done")
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tr.step_packed(batches[i % 8])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(tr.loss.cpu())
+    log(f"timed region: {elapsed:.4f} s for {args.steps} steps, loss {loss:.5f}")
+
+    # ---- dominant-kernel timing: HIP events around each launch of the same K steps, eager, on the launch stream
+    import ctypes as Cc
+    kt = {"srfrd_encoder_fwd": 0.0, "srfrd_encoder_bwd": 0.0, "srfrd_adam_step": 0.0}
+    if rank == 0:
+        kt = time_kernels(tr, batches, min(args.steps, 50))
+        log(f"kernel ms: {kt}")
+
+    if rank == 0:
+        lay = model.layout
+        T = B * L
+        fwd_fl = algorithmic_flops_per_token(L, lay.D, lay.d_item, lay.n_blocks) * T
+        dom = max(("srfrd_encoder_fwd", "srfrd_encoder_bwd"), key=lambda k: kt[k])
+        dom_flops = fwd_fl * (2 if dom.endswith("bwd") else 1)     # backward = 2x forward (train ~ 3x fwd)
+        dom_s = kt[dom] * 1e-3
+        achieved = dom_flops / dom_s / 1e12 if dom_s > 0 else 0.0
+        step_bytes = algorithmic_bytes_per_step(cfg["n_items"], L, B, lay.D, lay.d_item, lay.n_blocks, lay.n_dense)
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "sequences/sec", "value": world * B * args.steps / elapsed, "unit": "sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: SASRec train step (fwd + masked BCE + bwd + dense Adam), 50k items, seq_len 50, "
+                                   "batch 512 per GPU, hidden 50, 2 blocks, 1 head, dropout 0.5",
+                       "global_batch": world * B, "seq_len": L, "n_items": cfg["n_items"],
+                       "parallelism": f"dp{world}", "graph": not args.no_graph, "final_loss": loss},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_kernel_ms": kt[dom], "algorithmic_flops_per_launch": dom_flops,
+                         "kernel_ms": kt,
+                         "step_hbm": {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
+                                      "achieved": step_bytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": step_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def time_kernels(tr, batches, steps):
+    """Average duration (ms) of each launch, bracketed by events on the stream the launches go to."""
+    import ctypes as C
+    from srfrd_amd import _lib
+    from srfrd_amd._lib import check, ptr
+    names = ["srfrd_step_begin", "srfrd_encoder_fwd", "srfrd_encoder_bwd", "srfrd_reduce_dense", "srfrd_adam_step",
+             "srfrd_loss_finalize"]
+    lib = _lib.lib()
+    acc = {n: 0.0 for n in names}
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(steps)]
+    # re-use the trainer's own enqueue code, but with an event between launches: wrap the C entry points
+    orig = {n: getattr(lib, n) for n in names}
+    state = {"i": 0, "k": 0}
+
+    def wrap(n, k):
+        def f(*a):
+            rc = orig[n](*a)
+            ev[state["i"]][k + 1].record()
+            return rc
+        return f
+    for k, n in enumerate(names):
+        setattr(lib, n, wrap(n, k))
+    try:
+        torch.cuda.synchronize()
+        for i in range(steps):
+            state["i"] = i
+            tr.ids.copy_(batches[i % 8], non_blocking=True)
+            ev[i][0].record()
+            tr._enqueue_compute()
+            from srfrd_amd.trainer import flat_allreduce
+            if tr.world > 1:
+                flat_allreduce(tr.grad, tr.group)
+            tr._enqueue_update()
+        torch.cuda.synchronize()
+    finally:
+        for n in names:
+            setattr(lib, n, orig[n])
+    for i in range(steps):
+        for k, n in enumerate(names):
+            acc[n] += ev[i][k].elapsed_time(ev[i][k + 1])
+    return {n: acc[n] / steps for n in names}
+
+
+if __name__ == "__main__":
+    main()

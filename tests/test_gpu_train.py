@@ -1,0 +1,129 @@
+"""-m gpu: backward, Adam and the fused train step against the golden fixtures and the CPU oracle.
+Tolerances: gradients / loss 1e-4 absolute (fp32; observed ~1e-6); post-Adam weights 1e-4 with the K-bias slice
+excluded (tests/helpers.drop_kbias explains why that slice is rounding noise in any implementation)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import srfrd_oracle as O
+from tests.helpers import KINDS, drop_kbias, golden_cfg, load_golden, sub
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _loss(pl, nl, pos):
+    idx = torch.where(pos != 0)
+    crit = torch.nn.BCEWithLogitsLoss()
+    return crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_autograd_grads_match_golden(kind):
+    """reference trainer.py:35-40 driven through the drop-in module + torch autograd."""
+    from tests.gpu_util import build_model, cuda, maxerr
+    g, sd, batch = load_golden(kind)
+    cfg = golden_cfg(kind)
+    model = build_model(cfg, sd).train()            # dropout_rate = 0 in the golden config
+    seq, rsq, pos, prs, neg, nrs = cuda(*batch)
+    h, pl, nl = model(user_ids=None, input_ids=seq, fake_ids=rsq, positive_ids=pos, positive_fake_ids=prs,
+                      negative_ids=neg, negative_fake_ids=nrs)
+    loss = _loss(pl, nl, pos)
+    for p in model.parameters():                      # trainer.py:39 with l2_emb = 0.0
+        loss = loss + 0.0 * torch.norm(p)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss0"])) < TOL
+    gg = sub(g, "g/")
+    errs = {k: maxerr(p.grad, gg[k]) for k, p in model.named_parameters()}
+    bad = {k: v for k, v in errs.items() if not v < TOL}
+    assert not bad, f"gradient mismatch: {bad}"
+    assert set(errs) == set(gg)
+
+
+@pytest.mark.parametrize("kind", ["SASRec", "SRFRN"])
+def test_autograd_upstream_hidden_grad(kind):
+    """a loss on hidden_state itself (d_hidden path of the backward kernel) against oracle autograd."""
+    from tests.gpu_util import build_model, cuda, maxerr
+    g, sd, batch = load_golden(kind)
+    cfg = golden_cfg(kind)
+    model = build_model(cfg, sd).train()
+    seq, rsq, pos, prs, neg, nrs = cuda(*batch)
+    w = torch.randn(8, 20, cfg.d_out, generator=torch.Generator().manual_seed(1))
+    h, pl, nl = model(None, seq, rsq, pos, prs, neg, nrs)
+    ((h * w.cuda()).sum() + 0.5 * pl.sum() - 0.25 * nl.sum()).backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ho, plo, nlo = O.forward(cfg, leaves, *batch)
+    ((ho * w).sum() + 0.5 * plo.sum() - 0.25 * nlo.sum()).backward()
+    for k, p in model.named_parameters():
+        ref = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])
+        if k.endswith("item_embed.weight") or k == "item_emb.weight" or k.endswith("fake_embed.weight"):
+            ref = ref.clone()
+            ref[0] = 0            # padding_idx rows
+        assert maxerr(p.grad, ref) < 5e-4, k
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_trainer_matches_golden(kind, graph):
+    """3 fused steps (fwd + BCE + bwd + Adam) vs the reference's loss curve and post-step weights."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, maxerr
+    g, sd, batch = load_golden(kind)
+    cfg = golden_cfg(kind)
+    model = build_model(cfg, sd).train()
+    tr = srfrd_amd.FusedTrainer(model, 8, 20, lr=1e-3, betas=(0.9, 0.98), use_graph=graph)
+    seq, rsq, pos, prs, neg, nrs = cuda(*batch)
+    w1, w3 = sub(g, "w1/"), sub(g, "w3/")
+    for step in range(3):
+        loss = tr.step(None, seq, rsq, pos, prs, neg, nrs)
+        assert abs(float(loss.cpu()) - float(g[f"loss{step}"])) < TOL, step
+        if step == 0:
+            msd = model.state_dict()
+            for k in w1:
+                assert maxerr(drop_kbias(k, msd[k].cpu(), cfg.D), drop_kbias(k, w1[k], cfg.D)) < TOL, k
+    msd = model.state_dict()
+    for k in w3:
+        assert maxerr(drop_kbias(k, msd[k].cpu(), cfg.D), drop_kbias(k, w3[k], cfg.D)) < 2e-4, k
+
+
+@pytest.mark.parametrize("kind", ["SASRec", "SRFR", "SRFRN", "SRFU_B"])
+def test_dropout_train_mode_matches_oracle_masks(kind):
+    """p = 0.5: forward outputs and every gradient with the coordinate-hash masks the oracle rebuilds."""
+    from tests.gpu_util import build_model, cuda, maxerr
+    g, sd, batch = load_golden(kind)
+    cfg = golden_cfg(kind, dropout=0.5)
+    model = build_model(cfg, sd).train()
+    ids = model._prep(*cuda(*batch))
+    seed, seq0 = 0xC0FFEE, 40
+    out = model._launch_fwd(*ids, 0.5, seed, save=True, seq0=seq0)
+    ho, plo, nlo = O.forward(cfg, sd, *batch, train=True, seed=seed, b0=seq0)
+    assert maxerr(out["hidden"], ho) < TOL and maxerr(out["pos_logits"], plo) < TOL and maxerr(out["neg_logits"], nlo) < TOL
+    # gradients of  sum(0.3 * pos_logits - 0.2 * neg_logits)
+    dpl = torch.full_like(out["pos_logits"], 0.3)
+    dnl = torch.full_like(out["neg_logits"], -0.2)
+    gflat = model._launch_bwd(*ids, 0.5, seed, out, None, dpl, dnl, seq0=seq0)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    h2, p2, n2 = O.forward(cfg, leaves, *batch, train=True, seed=seed, b0=seq0)
+    (0.3 * p2.sum() - 0.2 * n2.sum()).backward()
+    named = dict(model.named_parameters())
+    for k, p in named.items():
+        off = next(o for q, o in model._slots if q is p)
+        got = gflat[off:off + p.numel()].view(p.shape)
+        ref = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])
+        if k.endswith("item_embed.weight") or k == "item_emb.weight" or k.endswith("fake_embed.weight"):
+            ref = ref.clone()
+            ref[0] = 0
+        assert maxerr(got, ref) < 2e-4, k
+
+
+def test_dropout_statistics_and_backward_consistency():
+    """keep rate ~ 1 - p, and two forwards with the same seed agree bit-for-bit while another seed differs."""
+    from tests.gpu_util import build_model, cuda
+    g, sd, batch = load_golden("SASRec")
+    cfg = golden_cfg("SASRec", dropout=0.5)
+    model = build_model(cfg, sd).train()
+    ids = model._prep(*cuda(*batch))
+    a = model._launch_fwd(*ids, 0.5, 11, save=False)["hidden"]
+    b = model._launch_fwd(*ids, 0.5, 11, save=False)["hidden"]
+    c = model._launch_fwd(*ids, 0.5, 12, save=False)["hidden"]
+    assert torch.equal(a, b) and not torch.equal(a, c)
