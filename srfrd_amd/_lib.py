@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsrfrd_hip.so")
+LIB_PATH = os.environ.get("SRFRD_LIB_PATH") or os.path.join(_HERE, "lib", "libsrfrd_hip.so")
 
 MAX_BLOCKS = 8
 MAX_D = 64

@@ -18,6 +18,10 @@
 namespace srfrd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// LDS-resident matrices are addressed through explicit address_space(3) pointers: a generic `float*` that the
+// compiler cannot trace back to __shared__ becomes flat_load/flat_store with 64-bit address arithmetic.
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) int lds_i;
 
 constexpr float kLnEps = 1e-8f;   // reference SRFR_model.py:77,80,86
 constexpr int kLdsLimit = 160 * 1024;
@@ -65,70 +69,135 @@ __device__ __forceinline__ float wave_max(float v) {
 // operand accessors: A(row, k) and B(k, col)
 // ---------------------------------------------------------------------------------------------
 struct Mat {            // element (r, c) of a row-major LDS matrix
-  const float* p;
+  const lds_f* p;
   int ld;
   __device__ __forceinline__ float operator()(int r, int c) const { return p[r * ld + c]; }
 };
 struct MatT {           // element (r, c) of the transpose of a row-major LDS matrix
-  const float* p;
+  const lds_f* p;
   int ld;
   __device__ __forceinline__ float operator()(int r, int c) const { return p[c * ld + r]; }
 };
 struct MatDrop {        // P with the attention-dropout multiplier applied on load (row = query, col = key)
-  const float* p;
+  const lds_f* p;
   int ld;
   DropSite ds;
   __device__ __forceinline__ float operator()(int r, int c) const { return p[r * ld + c] * drop_mul(ds, r, c); }
 };
 struct MatDropT {       // transpose of the above: element (key, query)
-  const float* p;
+  const lds_f* p;
   int ld;
   DropSite ds;
   __device__ __forceinline__ float operator()(int r, int c) const { return p[c * ld + r] * drop_mul(ds, c, r); }
 };
+struct MatOnes {        // [M | 1]: column `one_col` reads 1.0 - folds a column-sum (bias gradient) into a dW GEMM
+  const lds_f* p;
+  int ld, one_col;
+  __device__ __forceinline__ float operator()(int r, int c) const { return c == one_col ? 1.0f : p[r * ld + c]; }
+};
 struct WgtNT {          // B(k, n) = W[n][k]  (y = x W^T, torch Linear / Conv1d(k=1) weight (N, K)); 0 outside
   const float* w;
   int N, K;
-  __device__ __forceinline__ float operator()(int k, int n) const { return (n < N && k < K) ? w[n * K + k] : 0.0f; }
+  __device__ __forceinline__ float operator()(int k, int n) const {
+    const float v = w[min(n, N - 1) * K + min(k, K - 1)];     // clamped address + select: no branch in the MFMA loop
+    return (n < N && k < K) ? v : 0.0f;
+  }
 };
 struct WgtNN {          // B(k, n) = W[k][n]  (dx = dy W, weight (K, N)); 0 outside
   const float* w;
   int K, N;
-  __device__ __forceinline__ float operator()(int k, int n) const { return (k < K && n < N) ? w[k * N + n] : 0.0f; }
+  __device__ __forceinline__ float operator()(int k, int n) const {
+    const float v = w[min(k, K - 1) * N + min(n, N - 1)];
+    return (k < K && n < N) ? v : 0.0f;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
 // tiled GEMM on v_mfma_f32_16x16x4_f32.   C(16 mt.., 16 nt..) = sum_k A(row, k) * B(k, col)
 // A operand: lane l holds A[m0 + (l & 15)][k + (l >> 4)];  B operand: B[k + (l >> 4)][n0 + (l & 15)]
 // C/D: register r of lane l is element (m0 + 4 * (l >> 4) + r, n0 + (l & 15))
-// TRI: 0 full; 1 skip tiles with nt > mt (lower-triangular C); 2 k < 16 (mt + 1) (A lower-triangular);
-//      3 k >= 16 mt (A = transpose of a lower-triangular matrix)
+// TRI: 0 full; 1 skip tiles with nt > mt (lower-triangular C); 2 A is lower-triangular (k beyond the group's last
+//      diagonal block is skipped; inside the range the stored zeros of A do the masking); 3 A is the transpose of a
+//      lower-triangular matrix (k before the group's first diagonal block is skipped).
+//
+// Work split: a wave owns one 16-column strip (n-tile) and walks its row tiles in groups of G = 4 / 2 / 1, so a
+// B fragment (a weight column block from global/L1, or an LDS matrix) is loaded once per k-step and feeds G
+// independent accumulator chains (the 16x16x4 MFMA has a 40-cycle dependent latency against a 32-cycle issue
+// interval).  The inner body is branch-free: 4 B loads + 4G A loads are issued together, then 4G MFMAs.
+// When there are more waves than strips, the waves sharing a strip take interleaved row tiles.
 // ---------------------------------------------------------------------------------------------
+template <int G, class AL, class BL>
+__device__ __forceinline__ void mma_group(f32x4 (&acc)[G], const AL& a, const BL& b, int mrow, int mstride, int ncol,
+                                          int k0, int k1, int lq) {
+  int k = k0;
+  for (; k + 16 <= k1; k += 16) {
+    float bv[4], av[4][G];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bv[s] = b(k + 4 * s + lq, ncol);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < G; ++j) av[s][j] = a(mrow + j * mstride, k + 4 * s + lq);
+    // keep all 4 + 4G loads in flight ahead of the MFMAs (hipcc otherwise re-serialises load -> wait -> mfma)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][j], bv[s], acc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (; k < k1; k += 4) {
+    const float bv = b(k + lq, ncol);
+    float av[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) av[j] = a(mrow + j * mstride, k + lq);
+#pragma unroll
+    for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv, acc[j], 0, 0, 0);
+  }
+}
+
+template <int TRI, int G, class AL, class BL, class EPI>
+__device__ __forceinline__ void gemm_group(int mt, int mgroups, int n0, int k_end, const AL& a, const BL& b, const EPI& epi,
+                                           int li, int lq) {
+  int k0 = 0, k1 = k_end;
+  if (TRI == 2) k1 = min(k_end, (mt + (G - 1) * mgroups + 1) << 4);
+  if (TRI == 3) k0 = mt << 4;
+  f32x4 acc[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_group<G>(acc, a, b, (mt << 4) + li, mgroups << 4, n0 + li, k0, k1, lq);
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const int r0 = ((mt + j * mgroups) << 4) + (lq << 2), c = n0 + li;
+    epi(r0 + 0, c, acc[j][0]);
+    epi(r0 + 1, c, acc[j][1]);
+    epi(r0 + 2, c, acc[j][2]);
+    epi(r0 + 3, c, acc[j][3]);
+  }
+}
+
 template <int TRI, class AL, class BL, class EPI>
 __device__ __forceinline__ void gemm_tiles(int m_tiles, int n_tiles, int k_end, AL a, BL b, EPI epi) {
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
   const int li = lane & 15, lq = lane >> 4;
-  const int total = m_tiles * n_tiles;
-  for (int t = wave; t < total; t += nw) {
-    const int mt = t / n_tiles, nt = t - mt * n_tiles;
-    if (TRI == 1 && nt > mt) continue;
-    const int m0 = mt << 4, n0 = nt << 4;
-    int k0 = 0, k1 = k_end;
-    if (TRI == 2) k1 = min(k_end, (mt + 1) << 4);
-    if (TRI == 3) k0 = mt << 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k = k0; k < k1; k += 4) {
-      const float av = a(m0 + li, k + lq);
-      const float bv = b(k + lq, n0 + li);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+  const int mgroups = nw > n_tiles ? nw / n_tiles : 1;
+  const int units = n_tiles * mgroups;
+  for (int u = wave; u < units; u += nw) {
+    const int nt = u % n_tiles, g = u / n_tiles;
+    const int n0 = nt << 4;
+    int mt = g;
+    if (TRI == 1 && mt < nt) mt += ((nt - mt + mgroups - 1) / mgroups) * mgroups;   // first own row tile on/below the diagonal
+    while (mt + 3 * mgroups < m_tiles) {
+      gemm_group<TRI, 4>(mt, mgroups, n0, k_end, a, b, epi, li, lq);
+      mt += 4 * mgroups;
     }
-    const int r0 = m0 + (lq << 2), c = n0 + li;
-    epi(r0 + 0, c, acc[0]);
-    epi(r0 + 1, c, acc[1]);
-    epi(r0 + 2, c, acc[2]);
-    epi(r0 + 3, c, acc[3]);
+    if (mt + mgroups < m_tiles) {
+      gemm_group<TRI, 2>(mt, mgroups, n0, k_end, a, b, epi, li, lq);
+      mt += 2 * mgroups;
+    }
+    if (mt < m_tiles) gemm_group<TRI, 1>(mt, mgroups, n0, k_end, a, b, epi, li, lq);
   }
 }
 
@@ -136,9 +205,9 @@ __device__ __forceinline__ void gemm_tiles(int m_tiles, int n_tiles, int k_end, 
 // row-wise ops: one wave per row, lane = channel (D <= 64)
 // ---------------------------------------------------------------------------------------------
 // Y[r] = LayerNorm(X[r]) for r < rows   (biased variance, eps inside the sqrt: torch.nn.LayerNorm)
-__device__ __forceinline__ void ln_rows(const float* X, float* Y, int rows, int ld, int D, const float* w,
+__device__ __forceinline__ void ln_rows(const lds_f* X, lds_f* Y, int rows, int ld, int D, const float* w,
                                         const float* bia) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const float wl = lane < D ? w[lane] : 0.f, bl = lane < D ? bia[lane] : 0.f;
   const float invD = 1.0f / (float)D;
   for (int r = wave; r < rows; r += nw) {
@@ -156,9 +225,9 @@ __device__ __forceinline__ void ln_rows(const float* X, float* Y, int rows, int 
 //   OUT[r] = (ACCUM ? OUT[r] : 0) + dx ;  per-lane partial sums of dgamma = g*xhat, dbeta = g are returned in
 //   (dg, db) accumulated over the rows this wave handled.
 template <bool ACCUM>
-__device__ __forceinline__ void ln_bwd_rows(const float* GY, const float* X, float* OUT, int rows, int ld, int D,
+__device__ __forceinline__ void ln_bwd_rows(const lds_f* GY, const lds_f* X, lds_f* OUT, int rows, int ld, int D,
                                             const float* w, float& dg, float& db) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const float wl = lane < D ? w[lane] : 0.f;
   const float invD = 1.0f / (float)D;
   for (int r = wave; r < rows; r += nw) {

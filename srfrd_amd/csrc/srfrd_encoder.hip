@@ -36,7 +36,35 @@ struct EncArgs {
   int64_t dbg_slot;
 };
 
-__device__ __forceinline__ void tap(const EncArgs& a, int b, int slot, const float* buf, int rows, int cols, int ld) {
+// Optimisation barrier on a wave-uniform pointer: stops LLVM from hoisting the per-call-site address arithmetic of
+// ~35 inlined GEMMs out of the sequence / block loops (which costs > 256 VGPRs and spills).
+__device__ __forceinline__ void launder(lds_f*& p) {
+  asm volatile("" : "+s"(p));
+}
+__device__ __forceinline__ void launder(const float*& p) {
+  asm volatile("" : "+s"(p));
+}
+__device__ __forceinline__ void launder(float*& p) {
+  asm volatile("" : "+s"(p));
+}
+
+// Diagnostic build only (tools/phase_profile.py compiles a copy with -DSRFRD_STAMPS and a STAMP(n) after every
+// workgroup barrier): thread 0 adds the s_memtime delta of each phase into a per-workgroup table that aliases the
+// debug-tap buffer.  The shipped library contains no stamp.
+#ifdef SRFRD_STAMPS
+#define STAMP_INIT unsigned long long* stamp_acc = (unsigned long long*)a.dbg + (int64_t)blockIdx.x * 128; \
+                   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(id) do { if (threadIdx.x == 0 && a.dbg) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                       stamp_acc[id] += t_ - stamp_prev; stamp_prev = t_; } } while (0)
+#else
+#define STAMP_INIT
+#define STAMP(id) do {} while (0)
+#endif
+
+__device__ __forceinline__ void tap(const EncArgs& a, int b, int slot, const lds_f* buf, int rows, int cols, int ld) {
+#ifdef SRFRD_STAMPS
+  return;
+#endif
   if (a.dbg == nullptr || b != a.dbg_seq) return;
   float* dst = a.dbg + (int64_t)slot * a.dbg_slot;
   for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
@@ -78,23 +106,24 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const srfrd_layout& ly = a.lay;
   const Geom g = make_geom(a.L, ly.D);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nthr = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6, nthr = blockDim.x;
   const int L = g.L, LP = g.LP, D = g.D, DS = g.DS, SLD = g.SLD, NT = g.NT, MT = g.MT, DK = g.DK;
   const int szA = LP * DS, szX = imax(szA, LP * SLD);
-  float* bXS = smem;
-  float* bQN = bXS + szX;
-  float* bQ = bQN + szA;
-  float* bK = bQ + szA;
-  float* bV = bK + szA;
-  float* tail = bV + szA + kSlack;
-  int* s_in = (int*)tail;
-  float* s_keep = tail + LP;
-  int* s_pid = (int*)(tail + 2 * LP);
-  int* s_nid = (int*)(tail + 3 * LP);
-  float* s_misc = tail + 4 * LP;          // 64 floats
+  lds_f* const lds0 = (lds_f*)smem;
+  lds_f* bXS = lds0;
+  lds_f* bQN = bXS + szX;
+  lds_f* bQ = bQN + szA;
+  lds_f* bK = bQ + szA;
+  lds_f* bV = bK + szA;
+  lds_f* tail = bV + szA + kSlack;
+  lds_i* s_in = (lds_i*)tail;
+  lds_f* s_keep = tail + LP;
+  lds_i* s_pid = (lds_i*)(tail + 2 * LP);
+  lds_i* s_nid = (lds_i*)(tail + 3 * LP);
+  lds_f* s_misc = tail + 4 * LP;          // 64 floats
   {
     const int total = (int)fwd_lds_floats(g);
-    for (int i = tid; i < total; i += nthr) smem[i] = 0.f;
+    for (int i = tid; i < total; i += nthr) lds0[i] = 0.f;
   }
   __syncthreads();
 
@@ -110,6 +139,7 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
   const uint32_t seed = a.seed_dev ? *a.seed_dev : a.seed;
   const int B = a.B;
 
+  STAMP_INIT
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const int64_t rowbase = (int64_t)b * L;
     const uint32_t seq = (uint32_t)(a.seq0 + b);
@@ -122,14 +152,14 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
     }
     if (is_srfu && wave == 0) {
       const int lab = user_label_wave(kind, a.fk_ids ? a.fk_ids + rowbase : nullptr, L, ly.n_labels);
-      if (lane == 0) ((int*)s_misc)[0] = lab;
+      if (lane == 0) ((lds_i*)s_misc)[0] = lab;
     }
     __syncthreads();
 
     // ---- embedding: gather + position (+ side channel) + pad mask          
     {
       const DropSite dsE = drop_site(a.drop_on && is_sas, seed, SITE_EMB, seq, a.drop_thr, a.drop_scale);
-      const int lab = is_srfu ? ((int*)s_misc)[0] : 0;
+      const int lab = is_srfu ? ((lds_i*)s_misc)[0] : 0;
       for (int t = wave; t < L; t += nw) {
         if (lane < D) {
           const int id = s_in[t];
@@ -159,6 +189,7 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
     for (int i = 0; i < ly.n_blocks; ++i) {
       const srfrd_block_off o = ly.blk[i];
       const int tb = 1 + 8 * i;
+      launder(bXS); launder(bQN); launder(bQ); launder(bK); launder(bV);
       ln_rows(bXS, bQN, L, DS, D, P + o.ln1_w, P + o.ln1_b);
       __syncthreads();
       tap(a, b, tb + 0, bQN, L, D, DS);
@@ -180,7 +211,7 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
       {
         const DropSite dsA = drop_site(a.drop_on, seed, site_attn(i), seq, a.drop_thr, a.drop_scale);
         for (int r = wave; r < L; r += nw) {
-          float* row = bXS + r * SLD;
+          lds_f* row = bXS + r * SLD;
           float m = -INFINITY;
           for (int j = lane; j <= r; j += 64) m = fmaxf(m, row[j]);
           m = wave_max(m);
@@ -231,7 +262,7 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
     }
 
     // ---- head: (last_conv) -> last LayerNorm -> hidden, pos/neg logits, BCE partial sums
-    const float* hin = bXS;
+    const lds_f* hin = bXS;
     if (kind == SRFRD_SRFR) {
       gemm_tiles<0>(MT, (di + 15) >> 4, DK, Mat{bXS, DS}, WgtNT{P + ly.off_lc_w, di, D},
                     [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v + P[ly.off_lc_b + c]; });
@@ -291,8 +322,8 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
 // ================================================================================================
 // column sums over rows < L of an LDS matrix, added into a slab vector by ONE wave (fixed owner => the
 // read-modify-write on the slab is race-free and order-deterministic)
-__device__ __forceinline__ void colsum_to_slab(int owner_wave, const float* buf, int ld, int rows, int cols, float* dst) {
-  if ((int)(threadIdx.x >> 6) != owner_wave) return;
+__device__ __forceinline__ void colsum_to_slab(int owner_wave, const lds_f* buf, int ld, int rows, int cols, float* dst) {
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != owner_wave) return;
   const int lane = threadIdx.x & 63;
   if (lane < cols) {
     float s = 0.f;
@@ -302,8 +333,8 @@ __device__ __forceinline__ void colsum_to_slab(int owner_wave, const float* buf,
 }
 
 // per-wave (dgamma, dbeta) partials -> LDS -> wave 0 sums in wave order -> slab
-__device__ __forceinline__ void ln_param_grads_to_slab(float* s_red, float dg, float db, int cols, float* dst_w, float* dst_b) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+__device__ __forceinline__ void ln_param_grads_to_slab(lds_f* s_red, float dg, float db, int cols, float* dst_w, float* dst_b) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   s_red[(wave * 2 + 0) * 64 + lane] = dg;
   s_red[(wave * 2 + 1) * 64 + lane] = db;
   __syncthreads();
@@ -323,34 +354,35 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const srfrd_layout& ly = a.lay;
   const Geom g = make_geom(a.L, ly.D);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nthr = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6, nthr = blockDim.x;
   const int L = g.L, LP = g.LP, D = g.D, DS = g.DS, SLD = g.SLD, NT = g.NT, MT = g.MT, DK = g.DK;
   const int szA = LP * DS, szS = imax(LP * SLD, szA);
-  float* bX = smem;
-  float* bQN = bX + szA;
-  float* bQ = bQN + szA;
-  float* bK = bQ + szA;
-  float* bV = bK + szA;
-  float* bO = bV + szA;
-  float* bG = bO + szA;
-  float* bT = bG + szA;
-  float* S1 = bT + szA;
-  float* S2 = S1 + szS;
-  float* tail = S2 + szS + kSlack;
-  int* s_in = (int*)tail;
-  float* s_keep = tail + LP;
-  int* s_pid = (int*)(tail + 2 * LP);
-  int* s_nid = (int*)(tail + 3 * LP);
-  int* s_fk = (int*)(tail + 4 * LP);
-  int* s_pfk = (int*)(tail + 5 * LP);
-  int* s_nfk = (int*)(tail + 6 * LP);
-  float* s_dpl = tail + 7 * LP;
-  float* s_dnl = tail + 8 * LP;
-  float* s_misc = tail + 10 * LP;        // 64
-  float* s_red = s_misc + 64;            // 8 waves x 2 x 64
+  lds_f* const lds0 = (lds_f*)smem;
+  lds_f* bX = lds0;
+  lds_f* bQN = bX + szA;
+  lds_f* bQ = bQN + szA;
+  lds_f* bK = bQ + szA;
+  lds_f* bV = bK + szA;
+  lds_f* bO = bV + szA;
+  lds_f* bG = bO + szA;
+  lds_f* bT = bG + szA;
+  lds_f* S1 = bT + szA;
+  lds_f* S2 = S1 + szS;
+  lds_f* tail = S2 + szS + kSlack;
+  lds_i* s_in = (lds_i*)tail;
+  lds_f* s_keep = tail + LP;
+  lds_i* s_pid = (lds_i*)(tail + 2 * LP);
+  lds_i* s_nid = (lds_i*)(tail + 3 * LP);
+  lds_i* s_fk = (lds_i*)(tail + 4 * LP);
+  lds_i* s_pfk = (lds_i*)(tail + 5 * LP);
+  lds_i* s_nfk = (lds_i*)(tail + 6 * LP);
+  lds_f* s_dpl = tail + 7 * LP;
+  lds_f* s_dnl = tail + 8 * LP;
+  lds_f* s_misc = tail + 10 * LP;        // 64
+  lds_f* s_red = s_misc + 64;            // 8 waves x 2 x 64
   {
     const int total = (int)bwd_lds_floats(g);
-    for (int i = tid; i < total; i += nthr) smem[i] = 0.f;
+    for (int i = tid; i < total; i += nthr) lds0[i] = 0.f;
   }
   const float* P = a.dense;
   const float* table = a.table;
@@ -369,8 +401,19 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
   auto slab_rmw = [&](int64_t off, int R, int C) {
     return [=](int r, int c, float v) { if (r < R && c < C) slab[off + r * C + c] += v; };
   };
+  // dW (R x C at off_w) and, through the ones column C of the B operand, db (R at off_b) in one epilogue
+  auto slab_rmw_wb = [&](int64_t off_w, int64_t off_b, int R, int C) {
+    return [=](int r, int c, float v) {
+      if (r < R) {
+        if (c < C) slab[off_w + r * C + c] += v;
+        else if (c == C) slab[off_b + r] += v;
+      }
+    };
+  };
+  const bool fold_bias = (D & 15) != 0;       // a spare padded column exists in the last n-tile
   const float keep_scale = a.drop_on ? a.drop_scale : 1.0f;
 
+  STAMP_INIT
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const int64_t rowbase = (int64_t)b * L;
     const uint32_t seq = (uint32_t)(a.seq0 + b);
@@ -403,7 +446,7 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
     }
     if (is_srfu && wave == 0) {
       const int lab = user_label_wave(kind, a.fk_ids ? a.fk_ids + rowbase : nullptr, L, ly.n_labels);
-      if (lane == 0) ((int*)s_misc)[0] = lab;
+      if (lane == 0) ((lds_i*)s_misc)[0] = lab;
     }
     // final block output (input of last_conv / last LayerNorm) -> bX ; gradient pad rows must be exact zeros
     for (int i = tid; i < L * D; i += nthr) {
@@ -413,7 +456,7 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
     for (int i = tid; i < (LP - L) * DS; i += nthr) bG[L * DS + i] = 0.f;
     __syncthreads();
 
-    const float* lnin = bX;
+    const lds_f* lnin = bX;
     if (kind == SRFRD_SRFR) {
       gemm_tiles<0>(MT, (di + 15) >> 4, DK, Mat{bX, DS}, WgtNT{P + ly.off_lc_w, di, D},
                     [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v + P[ly.off_lc_b + c]; });
@@ -468,7 +511,7 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
       gemm_tiles<0>(MT, NT, (di + 3) & ~3, Mat{bG, DS}, WgtNN{P + ly.off_lc_w, di, D},
                     [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });
       __syncthreads();
-      float* t_ = bG; bG = bT; bT = t_;
+      lds_f* t_ = bG; bG = bT; bT = t_;
     }
     tap(a, b, 0, bG, L, D, DS);
 
@@ -478,6 +521,8 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
       const DropSite dsA = drop_site(a.drop_on, seed, site_attn(i), seq, a.drop_thr, a.drop_scale);
       const DropSite ds1 = drop_site(a.drop_on, seed, site_ffn1(i), seq, a.drop_thr, a.drop_scale);
       const DropSite ds2 = drop_site(a.drop_on, seed, site_ffn2(i), seq, a.drop_thr, a.drop_scale);
+      launder(bX); launder(bQN); launder(bQ); launder(bK); launder(bV); launder(bO); launder(bG); launder(bT);
+      launder(S1); launder(S2);
       // ================= FFN half: y = (drop2(a2) + h2) * keep, a2 = relu(drop1(h2 W1^T + b1)) W2^T + b2
       for (int idx = tid; idx < L * D; idx += nthr) {
         const int t = idx / D, c = idx - t * D;
@@ -495,14 +540,20 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
         if (c < D) bQ[r * DS + c] = fmaxf((v + P[o.c1_b + c]) * drop_mul(ds1, r, c), 0.f);   // r = relu(drop1(a1))
       });
       __syncthreads();
-      gemm_tiles<0>(NT, NT, LP, MatT{bK, DS}, Mat{bQ, DS}, slab_rmw(o.c2_w, D, D));           // dW2 += dA2^T r
-      colsum_to_slab(0, bK, DS, L, D, slab + o.c2_b);
+      if (fold_bias) gemm_tiles<0>(NT, NT, LP, MatT{bK, DS}, MatOnes{bQ, DS, D}, slab_rmw_wb(o.c2_w, o.c2_b, D, D));
+      else {
+        gemm_tiles<0>(NT, NT, LP, MatT{bK, DS}, Mat{bQ, DS}, slab_rmw(o.c2_w, D, D));         // dW2 += dA2^T r
+        colsum_to_slab(0, bK, DS, L, D, slab + o.c2_b);
+      }
       gemm_tiles<0>(MT, NT, DK, Mat{bK, DS}, WgtNN{P + o.c2_w, D, D}, [&](int r, int c, float v) {
         if (c < D) bV[r * DS + c] = bQ[r * DS + c] > 0.f ? v * keep_scale : 0.f;               // dA1
       });
       __syncthreads();
-      gemm_tiles<0>(NT, NT, LP, MatT{bV, DS}, Mat{bQN, DS}, slab_rmw(o.c1_w, D, D));           // dW1 += dA1^T h2
-      colsum_to_slab(1 % nw, bV, DS, L, D, slab + o.c1_b);
+      if (fold_bias) gemm_tiles<0>(NT, NT, LP, MatT{bV, DS}, MatOnes{bQN, DS, D}, slab_rmw_wb(o.c1_w, o.c1_b, D, D));
+      else {
+        gemm_tiles<0>(NT, NT, LP, MatT{bV, DS}, Mat{bQN, DS}, slab_rmw(o.c1_w, D, D));        // dW1 += dA1^T h2
+        colsum_to_slab(1 % nw, bV, DS, L, D, slab + o.c1_b);
+      }
       gemm_tiles<0>(MT, NT, DK, Mat{bV, DS}, WgtNN{P + o.c1_w, D, D},
                     [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });           // dh2 = dy + dA1 W1
       __syncthreads();
@@ -530,7 +581,7 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
       gemm_tiles<1>(MT, MT, DK, Mat{bQ, DS}, MatT{bK, DS}, [&](int r, int c, float v) { S1[r * SLD + c] = v; });
       __syncthreads();
       for (int r = wave; r < L; r += nw) {                       // P (dropout NOT folded in: applied on load)
-        float* row = S1 + r * SLD;
+        lds_f* row = S1 + r * SLD;
         float m = -INFINITY;
         for (int j = lane; j <= r; j += 64) m = fmaxf(m, row[j]);
         m = wave_max(m);
@@ -547,8 +598,11 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
       gemm_tiles<2>(MT, NT, LP, MatDrop{S1, SLD, dsA}, Mat{bV, DS},
                     [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });            // o = drop(P) v
       __syncthreads();
-      gemm_tiles<0>(NT, NT, LP, MatT{bG, DS}, Mat{bO, DS}, slab_rmw(o.out_w, D, D));           // dWo += dh1^T o
-      colsum_to_slab(2 % nw, bG, DS, L, D, slab + o.out_b);
+      if (fold_bias) gemm_tiles<0>(NT, NT, LP, MatT{bG, DS}, MatOnes{bO, DS, D}, slab_rmw_wb(o.out_w, o.out_b, D, D));
+      else {
+        gemm_tiles<0>(NT, NT, LP, MatT{bG, DS}, Mat{bO, DS}, slab_rmw(o.out_w, D, D));        // dWo += dh1^T o
+        colsum_to_slab(2 % nw, bG, DS, L, D, slab + o.out_b);
+      }
       __syncthreads();
       gemm_tiles<0>(MT, NT, DK, Mat{bG, DS}, WgtNN{P + o.out_w, D, D},
                     [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });            // do = dh1 Wo
@@ -558,9 +612,9 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
                     [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });            // dv = drop(P)^T do
       __syncthreads();
       for (int r = wave; r < LP; r += nw) {                      // dS = P * (dP - sum_j dP_j P_j), dP = mask * dPd
-        float* drow = S2 + r * SLD;
+        lds_f* drow = S2 + r * SLD;
         if (r < L) {
-          const float* prow = S1 + r * SLD;
+          const lds_f* prow = S1 + r * SLD;
           float acc = 0.f;
           for (int j = lane; j <= r; j += 64) {
             const float dp = drow[j] * drop_mul(dsA, r, j);
@@ -574,18 +628,24 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
         }
       }
       __syncthreads();
-      float* dKb = S1;                                           // P is dead: dk overlays it as [LP][DS]
+      lds_f* dKb = S1;                                           // P is dead: dk overlays it as [LP][DS]
       gemm_tiles<2>(MT, NT, LP, Mat{S2, SLD}, Mat{bK, DS},
                     [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v * qscale; });   // dq (pre-scale)
       gemm_tiles<3>(MT, NT, LP, MatT{S2, SLD}, Mat{bQ, DS},
                     [&](int r, int c, float v) { if (c < D) dKb[r * DS + c] = v; });           // dk = dS^T q
       __syncthreads();
-      gemm_tiles<0>(NT, NT, LP, MatT{bO, DS}, Mat{bQN, DS}, slab_rmw(o.in_w, D, D));           // dWq
-      colsum_to_slab(0, bO, DS, L, D, slab + o.in_b);
-      gemm_tiles<0>(NT, NT, LP, MatT{dKb, DS}, Mat{bX, DS}, slab_rmw(o.in_w + D * D, D, D));   // dWk
-      colsum_to_slab(1 % nw, dKb, DS, L, D, slab + o.in_b + D);
-      gemm_tiles<0>(NT, NT, LP, MatT{bT, DS}, Mat{bX, DS}, slab_rmw(o.in_w + 2 * D * D, D, D));  // dWv
-      colsum_to_slab(2 % nw, bT, DS, L, D, slab + o.in_b + 2 * D);
+      if (fold_bias) {                                                                          // dWq, dWk, dWv (+ biases)
+        gemm_tiles<0>(NT, NT, LP, MatT{bO, DS}, MatOnes{bQN, DS, D}, slab_rmw_wb(o.in_w, o.in_b, D, D));
+        gemm_tiles<0>(NT, NT, LP, MatT{dKb, DS}, MatOnes{bX, DS, D}, slab_rmw_wb(o.in_w + D * D, o.in_b + D, D, D));
+        gemm_tiles<0>(NT, NT, LP, MatT{bT, DS}, MatOnes{bX, DS, D}, slab_rmw_wb(o.in_w + 2 * D * D, o.in_b + 2 * D, D, D));
+      } else {
+        gemm_tiles<0>(NT, NT, LP, MatT{bO, DS}, Mat{bQN, DS}, slab_rmw(o.in_w, D, D));
+        colsum_to_slab(0, bO, DS, L, D, slab + o.in_b);
+        gemm_tiles<0>(NT, NT, LP, MatT{dKb, DS}, Mat{bX, DS}, slab_rmw(o.in_w + D * D, D, D));
+        colsum_to_slab(1 % nw, dKb, DS, L, D, slab + o.in_b + D);
+        gemm_tiles<0>(NT, NT, LP, MatT{bT, DS}, Mat{bX, DS}, slab_rmw(o.in_w + 2 * D * D, D, D));
+        colsum_to_slab(2 % nw, bT, DS, L, D, slab + o.in_b + 2 * D);
+      }
       gemm_tiles<0>(MT, NT, DK, Mat{bO, DS}, WgtNN{P + o.in_w, D, D},
                     [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });           // dLN1 = dh1 + dq Wq
       gemm_tiles<0>(MT, NT, DK, Mat{dKb, DS}, WgtNN{P + o.in_w + D * D, D, D},
@@ -598,7 +658,7 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
         ln_bwd_rows<true>(bG, bX, bQ, L, DS, D, P + o.ln1_w, dg, db);                          //     + LN1 bwd
         ln_param_grads_to_slab(s_red, dg, db, D, slab + o.ln1_w, slab + o.ln1_b);
       }
-      float* t_ = bG; bG = bQ; bQ = t_;
+      lds_f* t_ = bG; bG = bQ; bQ = t_;
       tap(a, b, tb + 1, bG, L, D, DS);
     }
 
@@ -625,7 +685,7 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
         }
       }
       if (is_srfu && wave == (1 % nw) && lane < D) {
-        const int lab = ((int*)s_misc)[0];
+        const int lab = ((lds_i*)s_misc)[0];
         float s = 0.f;
         for (int t = 0; t < L; ++t) s += bG[t * DS + lane] * s_keep[t];
         slab[ly.off_side + lab * D + lane] += s;
@@ -649,6 +709,14 @@ static int num_cu() {
       g_num_cu = 256;
   }
   return g_num_cu;
+}
+
+// block size override for tuning runs (multiple of 64, <= 512)
+static int env_threads(const char* name, int dflt) {
+  const char* e = getenv(name);
+  if (!e) return dflt;
+  const int v = atoi(e);
+  return (v >= 64 && v <= 512 && (v & 63) == 0) ? v : dflt;
 }
 
 static int fill_args(EncArgs& a, const srfrd_layout* lay, const float* item_table, const float* dense,
@@ -729,7 +797,7 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
   const int per_cu = (int)(kLdsLimit / lds) > 2 ? 2 : (int)(kLdsLimit / lds);
   int grid = num_cu() * (per_cu < 1 ? 1 : per_cu);
   if (grid > B) grid = B;
-  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(grid), dim3(256), (size_t)lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(grid), dim3(env_threads("SRFRD_FWD_THREADS", 256)), (size_t)lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -762,7 +830,7 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_tabl
     s_attr = lds;
   }
   const int grid = srfrd_bwd_grid(B);
-  hipLaunchKernelGGL(encoder_bwd_kernel, dim3(grid), dim3(512), (size_t)lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(encoder_bwd_kernel, dim3(grid), dim3(env_threads("SRFRD_BWD_THREADS", 512)), (size_t)lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

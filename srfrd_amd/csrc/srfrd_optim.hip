@@ -4,31 +4,43 @@
 
 namespace srfrd {
 
-// grad_dense[i] = sum_w slabs[w][i] in slab order (bitwise reproducible); block 0 also reduces the BCE partials.
+// grad_dense[i] = sum_w slabs[w][i]: a block owns 64 columns; its 4 waves each sum an interleaved quarter of the
+// slabs (4 loads in flight per lane), then the 4 partials are added in wave order - a fixed summation tree, so the
+// result is bitwise reproducible.  Block 0 also reduces the BCE partials.
 __global__ void __launch_bounds__(256) reduce_dense_kernel(const float* __restrict__ slabs, int n_slabs, int64_t n_dense,
                                                           float* __restrict__ grad_dense, const float* __restrict__ loss_part,
                                                           int B, float* __restrict__ stats) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n_dense) {
-    float s = 0.f;
-    for (int w = 0; w < n_slabs; ++w) s += slabs[(int64_t)w * n_dense + i];
-    grad_dense[i] = s;
+    int w = wave;
+    for (; w + 12 < n_slabs; w += 16) {
+      s0 += slabs[(int64_t)w * n_dense + i];
+      s1 += slabs[(int64_t)(w + 4) * n_dense + i];
+      s2 += slabs[(int64_t)(w + 8) * n_dense + i];
+      s3 += slabs[(int64_t)(w + 12) * n_dense + i];
+    }
+    for (; w < n_slabs; w += 4) s0 += slabs[(int64_t)w * n_dense + i];
   }
+  part[wave][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (wave == 0 && i < n_dense) grad_dense[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
   if (blockIdx.x == 0 && loss_part != nullptr && stats != nullptr) {
     __shared__ float red[4][3];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
-      s0 += loss_part[(int64_t)b * 3 + 0];
-      s1 += loss_part[(int64_t)b * 3 + 1];
-      s2 += loss_part[(int64_t)b * 3 + 2];
+      a0 += loss_part[(int64_t)b * 3 + 0];
+      a1 += loss_part[(int64_t)b * 3 + 1];
+      a2 += loss_part[(int64_t)b * 3 + 2];
     }
-    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; }
     __syncthreads();
     if (threadIdx.x < 3) {
       float s = 0.f;
-      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w][threadIdx.x];
+      for (int w = 0; w < 4; ++w) s += red[w][threadIdx.x];
       stats[threadIdx.x] = s;
     }
     if (threadIdx.x == 3) stats[3] = 0.f;
@@ -103,7 +115,7 @@ extern "C" int srfrd_reduce_dense(const float* grad_slabs, int n_slabs, int64_t 
                                   const float* loss_part, int B, float* stats, void* stream) {
   if (!grad_slabs || !grad_dense || n_slabs <= 0 || n_dense <= 0) return SRFRD_E_ARG;
   if ((loss_part != nullptr) != (stats != nullptr)) return SRFRD_E_ARG;
-  const int grid = (int)((n_dense + 255) / 256);
+  const int grid = (int)((n_dense + 63) / 64);
   hipLaunchKernelGGL(reduce_dense_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_slabs, n_slabs, n_dense,
                      grad_dense, loss_part, B, stats);
   return (int)hipGetLastError();

@@ -70,7 +70,7 @@ struct Cand {
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
 // k rounds of (argmax, remove) over `n` scores in LDS by one wave; writes k candidates
-__device__ __forceinline__ void wave_select_topk(float* sc, const int* ids, int n, int k, Cand* out) {
+__device__ __forceinline__ void wave_select_topk(lds_f* sc, const int* ids, int n, int k, Cand* out) {
   const int lane = threadIdx.x & 63;
   for (int r = 0; r < k; ++r) {
     float bv = -INFINITY;
@@ -107,10 +107,10 @@ __global__ void __launch_bounds__(256) topk_stage1_kernel(srfrd_layout ly, const
   const bool srfrn = ly.kind == SRFRD_SRFRN;
   const int DKi = (di + 3) & ~3, DSi = DKi + 2;
   const int SLD = kChunk + 2;
-  float* sE = smem;                       // [kChunk][DSi] item rows of this chunk
-  float* sH = sE + kChunk * DSi;          // [16][DSi]     last hidden state of 16 users (item part)
-  float* sS = sH + 16 * DSi;              // [16][SLD]     logits
-  float* sF = sS + 16 * SLD;              // [16]          SRFRN: <h[di:], fake_embed[label]> per user
+  lds_f* sE = (lds_f*)smem;               // [kChunk][DSi] item rows of this chunk
+  lds_f* sH = sE + kChunk * DSi;          // [16][DSi]     last hidden state of 16 users (item part)
+  lds_f* sS = sH + 16 * DSi;              // [16][SLD]     logits
+  lds_f* sF = sS + 16 * SLD;              // [16]          SRFRN: <h[di:], fake_embed[label]> per user
   const int chunk = blockIdx.x;
   const int64_t i0 = item_lo + (int64_t)chunk * kChunk;
   const int n_here = (int)((item_hi - i0) < kChunk ? (item_hi - i0) : kChunk);

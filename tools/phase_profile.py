@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the fused encoder kernels (diagnostic; run on the GPU box).
+
+Builds a copy of srfrd_encoder.hip with a STAMP(n) after every workgroup barrier of the two kernels
+(-DSRFRD_STAMPS), runs the C2 workload once through forward and backward, and prints for each barrier-delimited
+phase the mean s_memtime ticks per workgroup and its share.  Never used by the product, tests or bench.
+"""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "srfrd_amd", "csrc")
+OUT = os.path.join(ROOT, "srfrd_amd", "lib", "libsrfrd_hip_stamps.so")
+
+
+def build():
+    src = open(os.path.join(CSRC, "srfrd_encoder.hip")).read()
+    lines = src.split("\n")
+    out, labels, n, kernel = [], {}, 0, None
+    for ln, line in enumerate(lines):
+        out.append(line)
+        if "void __launch_bounds__(512) encoder_fwd_kernel" in line:
+            kernel, n = "fwd", 0
+        elif "void __launch_bounds__(512) encoder_bwd_kernel" in line:
+            kernel, n = "bwd", 0
+        elif line == "}":
+            kernel = None
+        if kernel and line.strip() == "__syncthreads();" and n < 120:
+            # only inside the sequence loop (after STAMP_INIT of this kernel)
+            seen_init = any("STAMP_INIT" in l for l in out[-4000:] if True) and _after_init(out, kernel)
+            if seen_init:
+                prev = next((l.strip() for l in reversed(lines[:ln]) if l.strip() and l.strip() != "__syncthreads();"), "")
+                out.append(f"    STAMP({n});")
+                labels[(kernel, n)] = f"L{ln + 1}: {prev[:90]}"
+                n += 1
+    tmp = "/tmp/srfrd_stamps"
+    os.makedirs(tmp + "/srfrd_amd/csrc", exist_ok=True)
+    os.makedirs(tmp + "/include", exist_ok=True)
+    for f in ("srfrd_dev.h", "srfrd_rng.h", "srfrd_optim.hip", "srfrd_rank.hip"):
+        open(f"{tmp}/srfrd_amd/csrc/{f}", "w").write(open(os.path.join(CSRC, f)).read())
+    open(f"{tmp}/include/srfrd_hip.h", "w").write(open(os.path.join(ROOT, "include", "srfrd_hip.h")).read())
+    open(f"{tmp}/srfrd_amd/csrc/srfrd_encoder.hip", "w").write("\n".join(out))
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
+           "-DSRFRD_STAMPS", "-o", OUT] + [f"{tmp}/srfrd_amd/csrc/{f}" for f in ("srfrd_encoder.hip", "srfrd_optim.hip", "srfrd_rank.hip")]
+    subprocess.run(cmd, check=True)
+    import json
+    json.dump({f"{k[0]}:{k[1]}": v for k, v in labels.items()}, open(OUT + ".labels.json", "w"), indent=0)
+
+
+def _after_init(out, kernel):
+    # walk back to the kernel header; True if a STAMP_INIT line was emitted after it
+    for l in reversed(out):
+        if l.strip() == "STAMP_INIT":
+            return True
+        if "__launch_bounds__(512) encoder_" in l:
+            return False
+    return False
+
+
+def run():
+    import json
+    import torch
+    os.environ["SRFRD_LIB_PATH"] = OUT
+    import srfrd_amd
+    from srfrd_amd import _lib
+    labels = json.load(open(OUT + ".labels.json"))
+    I, L, B, D = 50_000, 50, 512, 50
+    torch.manual_seed(0)
+    m = srfrd_amd.SASRec(I, L, D, 0.5, 2, 1, "cuda")
+    for _, p in m.named_parameters():
+        if p.dim() >= 2:
+            torch.nn.init.xavier_normal_(p.data)
+    m = m.cuda().train()
+    _, seq, rsq, pos, prs, neg, nrs = srfrd_amd.synthetic_batch(I, L, B, seed=1, device="cuda")
+    ids = m._prep(seq, None, pos, None, neg, None)
+    for which in ("fwd", "bwd"):
+        dbg = torch.zeros(1024, 128, device="cuda", dtype=torch.int64)
+        out = m._launch_fwd(*ids, 0.5, 7, save=True, dbg=dbg.view(torch.float32) if which == "fwd" else None)
+        if which == "bwd":
+            dpl = torch.full_like(out["pos_logits"], 0.1)
+            m._launch_bwd(*ids, 0.5, 7, out, None, dpl, dpl, dbg=dbg.view(torch.float32))
+        torch.cuda.synchronize()
+        d = dbg.cpu().double()
+        used = d[d.sum(1) > 0]
+        mean = used.mean(0)
+        tot = float(mean.sum())
+        print(f"== {which}: {used.shape[0]} workgroups, {tot:.0f} ticks (100 MHz -> {tot / 100:.1f} us) per workgroup")
+        for i in range(128):
+            if mean[i] > 0:
+                print(f"  {i:3d} {float(mean[i]):9.0f} {100 * float(mean[i]) / tot:5.1f}%  {labels.get(f'{which}:{i}', '')}")
+
+
+if __name__ == "__main__":
+    if "--build" in sys.argv:
+        build()
+    if "--run" in sys.argv:
+        run()
