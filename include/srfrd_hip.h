@@ -87,12 +87,21 @@ int srfrd_bwd_grid(int B);
 int srfrd_debug_shape(const srfrd_layout* lay, int L, int64_t* slot_floats, int32_t* n_slots);
 
 /*
+ * Weight packing.  The fused kernels read every (out, in) weight matrix of the encoder (in_proj's three slices,
+ * out_proj, conv1, conv2, last_conv) from `packed`: a copy pre-swizzled into v_mfma_f32_16x16x4_f32 B-fragment order
+ * in both product forms (x W^T for the forward, dy W for the backward).  Call after every parameter update and before
+ * srfrd_encoder_fwd / _bwd.  packed holds srfrd_packed_floats(lay) floats.
+ */
+int64_t srfrd_packed_floats(const srfrd_layout* lay);
+int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packed, void* stream);
+
+/*
  * Fused forward: embedding gather (+pos, +fake / user-label channel, pad mask), n_blocks x
  * {LN -> causal self-attention -> +res -> LN -> PW-FFN -> mask}, (last_conv), last LN, pos/neg logits and the
  * masked-BCE partial sums.  Replaces reference SRFR_model.py:92-142 (and the SRFRN / SRFU / SASRec twins)
  * plus the loss terms of reference trainer.py:36-38.
  *
- *  item_table (n_items+1, d_item), dense (n_dense)           parameters
+ *  item_table (n_items+1, d_item), dense (n_dense)           parameters;  packed: srfrd_pack_weights(dense)
  *  input_ids, fake_ids (B,L); fake_ids may be NULL (SASRec ignores it; SRFR/SRFRN treat NULL as all-zero,
  *    reference SRFR_model.py:27-28)
  *  pos_ids/neg_ids (B,L) or NULL (no logits, reference :126-136); pos_fake/neg_fake used by SRFRN only
@@ -104,7 +113,7 @@ int srfrd_debug_shape(const srfrd_layout* lay, int L, int64_t* slot_floats, int3
  *  loss_part (B,3) or NULL: per sequence {sum softplus(-pos), sum softplus(neg), count} over pos_ids != 0
  *  dbg / dbg_seq: debug taps of one sequence (tests only; NULL otherwise)
  */
-int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const float* dense,
+int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
                       const int64_t* input_ids, const int64_t* fake_ids,
                       const int64_t* pos_ids, const int64_t* pos_fake,
                       const int64_t* neg_ids, const int64_t* neg_fake,
@@ -123,7 +132,7 @@ int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const fl
  *  grad_table (n_items+1, d_item): += by float atomics (caller zeroes it; row 0 never written: padding_idx)
  *  grad_slabs (srfrd_bwd_grid(B), n_dense): per-workgroup partial dense gradients (fully overwritten)
  */
-int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const float* dense,
+int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
                       const int64_t* input_ids, const int64_t* fake_ids,
                       const int64_t* pos_ids, const int64_t* pos_fake,
                       const int64_t* neg_ids, const int64_t* neg_fake,

@@ -112,6 +112,33 @@ struct WgtNN {          // B(k, n) = W[k][n]  (dx = dy W, weight (K, N)); 0 outs
   }
 };
 
+// Weights pre-swizzled into MFMA B-fragment order by srfrd_pack_weights: for strip nt and 16-deep k-chunk kc, lane l
+// holds the float4 {B(16kc + 4s + (l>>4), 16nt + (l&15))}_{s=0..3}, zero outside the matrix.  One coalesced
+// global_load_dwordx4 per lane per chunk replaces four predicated scalar gathers, and a whole strip (<= 4 chunks
+// at D <= 64) is requested up front, so a weight GEMM exposes one L2 latency instead of one per k-chunk.
+constexpr int kPackKC = 4;                     // k-chunks per strip (K <= 64)
+constexpr int kPackFloats = 4 * kPackKC * 256; // floats per packed matrix-form (4 strips)
+struct PackedB {
+  const float4* p;
+  __device__ __forceinline__ float4 chunk(int nt, int kc, int lane) const { return p[(nt * kPackKC + kc) * 64 + lane]; }
+};
+
+// dW epilogue: read-modify-write of a (R x C) weight-gradient block (+ the bias gradient in column C, fed by the
+// ones column of MatOnes) in this workgroup's slab.  The old values are requested BEFORE the MFMA chain so their
+// latency hides under it; `rmw == 0` (first sequence of the workgroup: the slab is still zero) skips the loads.
+struct SlabWB {
+  float* w;
+  float* b;      // may be null
+  int R, C, rmw;
+  __device__ __forceinline__ float* ptr(int r, int c) const {
+    if (r < R) {
+      if (c < C) return w + r * C + c;
+      if (c == C && b != nullptr) return b + r;
+    }
+    return nullptr;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // tiled GEMM on v_mfma_f32_16x16x4_f32.   C(16 mt.., 16 nt..) = sum_k A(row, k) * B(k, col)
 // A operand: lane l holds A[m0 + (l & 15)][k + (l >> 4)];  B operand: B[k + (l >> 4)][n0 + (l & 15)]
@@ -176,6 +203,129 @@ __device__ __forceinline__ void gemm_group(int mt, int mgroups, int n0, int k_en
   }
 }
 
+// slab (dW) variant of gemm_group: preloads C, always full k range
+template <int G, class AL, class BL>
+__device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int k_end, const AL& a, const BL& b,
+                                                const SlabWB& sl, int li, int lq) {
+  float* ptrs[G][4];
+  float old[G][4];
+#pragma unroll
+  for (int j = 0; j < G; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ptrs[j][e] = sl.ptr(((mt + j * mgroups) << 4) + (lq << 2) + e, n0 + li);
+      old[j][e] = (sl.rmw && ptrs[j][e] != nullptr) ? *ptrs[j][e] : 0.f;
+    }
+  f32x4 acc[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_group<G>(acc, a, b, (mt << 4) + li, mgroups << 4, n0 + li, 0, k_end, lq);
+#pragma unroll
+  for (int j = 0; j < G; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (ptrs[j][e] != nullptr) *ptrs[j][e] = old[j][e] + acc[j][e];
+}
+
+template <class AL, class BL>
+__device__ __forceinline__ void gemm_slab(int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int mgroups = nw > n_tiles ? nw / n_tiles : 1;
+  const int units = n_tiles * mgroups;
+  for (int u = wave; u < units; u += nw) {
+    const int nt = u % n_tiles, g = u / n_tiles;
+    const int n0 = nt << 4;
+    int mt = g;
+    while (mt + 3 * mgroups < m_tiles) {
+      gemm_group_slab<4>(mt, mgroups, n0, k_end, a, b, sl, li, lq);
+      mt += 4 * mgroups;
+    }
+    if (mt + mgroups < m_tiles) {
+      gemm_group_slab<2>(mt, mgroups, n0, k_end, a, b, sl, li, lq);
+      mt += 2 * mgroups;
+    }
+    if (mt < m_tiles) gemm_group_slab<1>(mt, mgroups, n0, k_end, a, b, sl, li, lq);
+  }
+}
+
+// packed-weight variant: C = A * Bpacked (+ bias[col]); k_end <= 64 and a multiple of 4
+template <int G, class AL, class EPI>
+__device__ __forceinline__ void gemm_group_packed(int mt, int mgroups, int nt, int k_end, const AL& a, const PackedB& b,
+                                                  const float* bias, int nbias, const EPI& epi, int lane) {
+  const int li = lane & 15, lq = lane >> 4;
+  const int n0 = nt << 4;
+  float4 bq[kPackKC];
+#pragma unroll
+  for (int kc = 0; kc < kPackKC; ++kc) bq[kc] = b.chunk(nt, kc, lane);
+  const float bias_v = (bias != nullptr && n0 + li < nbias) ? bias[n0 + li] : 0.f;
+  f32x4 acc[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int mrow = (mt << 4) + li, mstride = mgroups << 4;
+#pragma unroll
+  for (int kc = 0; kc < kPackKC; ++kc) {
+    const int kb = kc << 4;
+    if (kb + 16 <= k_end) {
+      float av[4][G];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < G; ++j) av[s][j] = a(mrow + j * mstride, kb + 4 * s + lq);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][j], bq[kc][s], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    } else if (kb < k_end) {
+      const int nst = (k_end - kb) >> 2;     // 1..3 tail steps
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        if (s < nst) {
+          float av[G];
+#pragma unroll
+          for (int j = 0; j < G; ++j) av[j] = a(mrow + j * mstride, kb + 4 * s + lq);
+#pragma unroll
+          for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[kc][s], acc[j], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const int r0 = ((mt + j * mgroups) << 4) + (lq << 2), c = n0 + li;
+    epi(r0 + 0, c, acc[j][0] + bias_v);
+    epi(r0 + 1, c, acc[j][1] + bias_v);
+    epi(r0 + 2, c, acc[j][2] + bias_v);
+    epi(r0 + 3, c, acc[j][3] + bias_v);
+  }
+}
+
+template <class AL, class EPI>
+__device__ __forceinline__ void gemm_packed(int m_tiles, int n_tiles, int k_end, AL a, PackedB b, const float* bias, int nbias,
+                                            EPI epi) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = blockDim.x >> 6;
+  const int mgroups = nw > n_tiles ? nw / n_tiles : 1;
+  const int units = n_tiles * mgroups;
+  for (int u = wave; u < units; u += nw) {
+    const int nt = u % n_tiles, g = u / n_tiles;
+    int mt = g;
+    while (mt + 3 * mgroups < m_tiles) {
+      gemm_group_packed<4>(mt, mgroups, nt, k_end, a, b, bias, nbias, epi, lane);
+      mt += 4 * mgroups;
+    }
+    if (mt + mgroups < m_tiles) {
+      gemm_group_packed<2>(mt, mgroups, nt, k_end, a, b, bias, nbias, epi, lane);
+      mt += 2 * mgroups;
+    }
+    if (mt < m_tiles) gemm_group_packed<1>(mt, mgroups, nt, k_end, a, b, bias, nbias, epi, lane);
+  }
+}
+
 template <int TRI, class AL, class BL, class EPI>
 __device__ __forceinline__ void gemm_tiles(int m_tiles, int n_tiles, int k_end, AL a, BL b, EPI epi) {
   const int lane = threadIdx.x & 63;
@@ -202,51 +352,167 @@ __device__ __forceinline__ void gemm_tiles(int m_tiles, int n_tiles, int k_end, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// row-wise ops: one wave per row, lane = channel (D <= 64)
+// row-wise ops: FOUR lanes (one DPP quad) per row, lane q owns columns q, q + 4, q + 8, ...  A 256-thread
+// workgroup therefore covers 64 rows per pass, every row's loads are in flight at once, and the reductions are two
+// DPP quad_perm adds (VALU rate) instead of six dependent ds_bpermute shuffles per row per reduction.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // lane ^ 1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // lane ^ 2
+  return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  return v;
+}
+
+constexpr int kQC = SRFRD_MAX_D / 4;    // columns per lane of a quad (D <= 64)
+
 // Y[r] = LayerNorm(X[r]) for r < rows   (biased variance, eps inside the sqrt: torch.nn.LayerNorm)
 __device__ __forceinline__ void ln_rows(const lds_f* X, lds_f* Y, int rows, int ld, int D, const float* w,
                                         const float* bia) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-  const float wl = lane < D ? w[lane] : 0.f, bl = lane < D ? bia[lane] : 0.f;
+  const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
   const float invD = 1.0f / (float)D;
-  for (int r = wave; r < rows; r += nw) {
-    const float x = lane < D ? X[r * ld + lane] : 0.f;
-    const float mu = wave_sum(x) * invD;
-    const float xc = lane < D ? x - mu : 0.f;
-    const float var = wave_sum(xc * xc) * invD;
-    const float rstd = 1.0f / sqrtf(var + kLnEps);
-    if (lane < D) Y[r * ld + lane] = xc * rstd * wl + bl;
+  float wl[kQC], bl[kQC];
+#pragma unroll
+  for (int j = 0; j < kQC; ++j) {
+    const int c = q + 4 * j;
+    wl[j] = c < D ? w[c] : 0.f;
+    bl[j] = c < D ? bia[c] : 0.f;
+  }
+  for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
+    float x[kQC];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kQC; ++j) {
+      const int c = q + 4 * j;
+      x[j] = c < D ? X[r * ld + c] : 0.f;
+      s += x[j];
+    }
+    const float mu = quad_sum(s) * invD;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < kQC; ++j) {
+      const int c = q + 4 * j;
+      x[j] = c < D ? x[j] - mu : 0.f;
+      v += x[j] * x[j];
+    }
+    const float rstd = 1.0f / sqrtf(quad_sum(v) * invD + kLnEps);
+#pragma unroll
+    for (int j = 0; j < kQC; ++j) {
+      const int c = q + 4 * j;
+      if (c < D) Y[r * ld + c] = x[j] * rstd * wl[j] + bl[j];
+    }
   }
 }
 
-// LayerNorm backward for rows < rows:  G[r] <- dX (in place, or G[r] += dX when ACCUM) given upstream G? no:
-//   g = GY[r] (upstream), x = X[r];  dx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat))
-//   OUT[r] = (ACCUM ? OUT[r] : 0) + dx ;  per-lane partial sums of dgamma = g*xhat, dbeta = g are returned in
-//   (dg, db) accumulated over the rows this wave handled.
+// LayerNorm backward, rows < rows.  g = GY[r] (upstream), x = X[r]:
+//   dx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat));  OUT[r] = (ACCUM ? OUT[r] : 0) + dx   (OUT must not alias GY)
+//   GXH[r] = g * xhat  -- its column sums are dgamma, those of GY are dbeta; both are taken on the matrix cores by the
+//   caller (ones-row GEMM), so this pass needs no cross-row reduction.
 template <bool ACCUM>
-__device__ __forceinline__ void ln_bwd_rows(const lds_f* GY, const lds_f* X, lds_f* OUT, int rows, int ld, int D,
-                                            const float* w, float& dg, float& db) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
-  const float wl = lane < D ? w[lane] : 0.f;
+__device__ __forceinline__ void ln_bwd_rows(const lds_f* GY, const lds_f* X, lds_f* OUT, lds_f* GXH, int rows, int LP, int ld,
+                                            int D, const float* w) {
+  const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
+  for (int i = threadIdx.x; i < (LP - rows) * ld; i += blockDim.x) GXH[rows * ld + i] = 0.f;   // padding rows feed a k-sum
   const float invD = 1.0f / (float)D;
-  for (int r = wave; r < rows; r += nw) {
-    const float x = lane < D ? X[r * ld + lane] : 0.f;
-    const float g = lane < D ? GY[r * ld + lane] : 0.f;
-    const float mu = wave_sum(x) * invD;
-    const float xc = lane < D ? x - mu : 0.f;
-    const float var = wave_sum(xc * xc) * invD;
-    const float rstd = 1.0f / sqrtf(var + kLnEps);
-    const float xh = xc * rstd;
-    const float gw = g * wl;
-    const float m1 = wave_sum(gw) * invD;
-    const float m2 = wave_sum(gw * xh) * invD;
-    const float dx = rstd * (gw - m1 - xh * m2);
-    dg += g * xh;
-    db += g;
-    if (lane < D) {
-      if (ACCUM) OUT[r * ld + lane] += dx;
-      else OUT[r * ld + lane] = dx;
+  float wl[kQC];
+#pragma unroll
+  for (int j = 0; j < kQC; ++j) {
+    const int c = q + 4 * j;
+    wl[j] = c < D ? w[c] : 0.f;
+  }
+  for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
+    float x[kQC], g[kQC];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kQC; ++j) {
+      const int c = q + 4 * j;
+      x[j] = c < D ? X[r * ld + c] : 0.f;
+      g[j] = c < D ? GY[r * ld + c] : 0.f;
+      s += x[j];
+    }
+    const float mu = quad_sum(s) * invD;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < kQC; ++j) {
+      const int c = q + 4 * j;
+      x[j] = c < D ? x[j] - mu : 0.f;
+      v += x[j] * x[j];
+    }
+    const float rstd = 1.0f / sqrtf(quad_sum(v) * invD + kLnEps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kQC; ++j) {
+      x[j] *= rstd;                       // xhat
+      const float gw = g[j] * wl[j];
+      s1 += gw;
+      s2 += gw * x[j];
+    }
+    const float m1 = quad_sum(s1) * invD, m2 = quad_sum(s2) * invD;
+#pragma unroll
+    for (int j = 0; j < kQC; ++j) {
+      const int c = q + 4 * j;
+      if (c < D) {
+        const float dx = rstd * (g[j] * wl[j] - m1 - x[j] * m2);
+        if (ACCUM) OUT[r * ld + c] += dx;
+        else OUT[r * ld + c] = dx;
+        GXH[r * ld + c] = g[j] * x[j];
+      }
+    }
+  }
+}
+
+struct OnesRow {        // A operand whose row 0 is all ones (rows 1..15 zero): C row 0 = column sums of B
+  __device__ __forceinline__ float operator()(int r, int) const { return r == 0 ? 1.0f : 0.0f; }
+};
+
+// causal softmax of score rows r < rows in place; keys j > r get exact zeros up to LP.  MASKED folds the attention
+// dropout multiplier into the stored probabilities (forward); the backward keeps P unmasked and masks on load.
+template <bool MASKED>
+__device__ __forceinline__ void softmax_rows(lds_f* S, int rows, int sld, int LP, const DropSite& ds) {
+  const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
+  for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
+    lds_f* row = S + r * sld;
+    float m = -INFINITY;
+    for (int j = q; j <= r; j += 4) m = fmaxf(m, row[j]);
+    m = quad_max(m);
+    float s = 0.f;
+    for (int j = q; j <= r; j += 4) {
+      const float e = expf(row[j] - m);
+      row[j] = e;
+      s += e;
+    }
+    s = quad_sum(s);
+    for (int j = q; j < LP; j += 4) {
+      float p = 0.f;
+      if (j <= r) {
+        p = row[j] / s;
+        if (MASKED) p *= drop_mul(ds, r, j);
+      }
+      row[j] = p;
+    }
+  }
+}
+
+// dS = P * (dP - sum_j dP_j P_j), dP = mask * dPd, in place in dPd; rows >= rows (padding) are zeroed up to LP rows
+__device__ __forceinline__ void softmax_bwd_rows(lds_f* dPd, const lds_f* P, int rows, int sld, int LP, const DropSite& ds) {
+  const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
+  for (int r = threadIdx.x >> 2; r < LP; r += rpp) {
+    lds_f* drow = dPd + r * sld;
+    if (r < rows) {
+      const lds_f* prow = P + r * sld;
+      float acc = 0.f;
+      for (int j = q; j <= r; j += 4) {
+        const float dp = drow[j] * drop_mul(ds, r, j);
+        drow[j] = dp;
+        acc += dp * prow[j];
+      }
+      acc = quad_sum(acc);
+      for (int j = q; j < LP; j += 4) drow[j] = j <= r ? prow[j] * (drow[j] - acc) : 0.f;
+    } else {
+      for (int j = q; j < LP; j += 4) drow[j] = 0.f;
     }
   }
 }

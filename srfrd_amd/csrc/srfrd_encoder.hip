@@ -15,6 +15,7 @@ struct EncArgs {
   srfrd_layout lay;
   const float* table;
   const float* dense;
+  const float* packed;      // srfrd_pack_weights output (MFMA-fragment-ordered weights)
   const int64_t *in_ids, *fk_ids, *pos_ids, *pos_fk, *neg_ids, *neg_fk;
   int B, L;
   uint32_t seed;
@@ -138,6 +139,10 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
   const float qscale = a.qscale;
   const uint32_t seed = a.seed_dev ? *a.seed_dev : a.seed;
   const int B = a.B;
+  // packed weight of matrix `mat` (block*6 + {Wq,Wk,Wv,Wo,W1,W2}; n_blocks*6 = last_conv); form 0: x W^T, 1: dy W
+  auto pk = [&](int mat, int form) {
+    return PackedB{reinterpret_cast<const float4*>(a.packed) + ((int64_t)mat * 2 + form) * (kPackFloats / 4)};
+  };
 
   STAMP_INIT
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -160,26 +165,30 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
     {
       const DropSite dsE = drop_site(a.drop_on && is_sas, seed, SITE_EMB, seq, a.drop_thr, a.drop_scale);
       const int lab = is_srfu ? ((lds_i*)s_misc)[0] : 0;
-      for (int t = wave; t < L; t += nw) {
-        if (lane < D) {
-          const int id = s_in[t];
-          float v;
-          if (has_fake) {
-            if (lane < di) v = table[(int64_t)id * di + lane] + P[ly.off_pos + t * di + lane];
-            else {
-              const int f = a.fk_ids ? (int)a.fk_ids[rowbase + t] : 0;
-              v = P[ly.off_side + f * dfk + (lane - di)];
+      const int q = tid & 3;
+      for (int t = tid >> 2; t < L; t += nthr >> 2) {                  // one DPP quad per position
+        const int id = s_in[t];
+        const float keep = s_keep[t];
+        const int f = (has_fake && a.fk_ids) ? (int)a.fk_ids[rowbase + t] : 0;
+#pragma unroll
+        for (int j = 0; j < kQC; ++j) {
+          const int c = q + 4 * j;
+          if (c < D) {
+            float v;
+            if (has_fake) {
+              if (c < di) v = table[(int64_t)id * di + c] + P[ly.off_pos + t * di + c];
+              else v = P[ly.off_side + f * dfk + (c - di)];
+            } else {
+              v = table[(int64_t)id * di + c];
+              if (is_sas) v *= sqrtD;
+              v += P[ly.off_pos + t * di + c];
+              if (is_srfu) v += P[ly.off_side + lab * D + c];
+              if (is_sas) v *= drop_mul(dsE, t, c);
             }
-          } else {
-            v = table[(int64_t)id * di + lane];
-            if (is_sas) v *= sqrtD;
-            v += P[ly.off_pos + t * di + lane];
-            if (is_srfu) v += P[ly.off_side + lab * D + lane];
-            if (is_sas) v *= drop_mul(dsE, t, lane);
+            v *= keep;
+            bXS[t * DS + c] = v;
+            if (a.save_x) a.save_x[(rowbase + t) * D + c] = v;
           }
-          v *= s_keep[t];
-          bXS[t * DS + lane] = v;
-          if (a.save_x) a.save_x[(rowbase + t) * D + lane] = v;
         }
       }
     }
@@ -194,12 +203,12 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
       __syncthreads();
       tap(a, b, tb + 0, bQN, L, D, DS);
       // q = (LN(x) Wq^T + bq) * sqrt(1/d_h);  k = x Wk^T + bk;  v = x Wv^T + bv
-      gemm_tiles<0>(MT, NT, DK, Mat{bQN, DS}, WgtNT{P + o.in_w, D, D},
-                    [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = (v + P[o.in_b + c]) * qscale; });
-      gemm_tiles<0>(MT, NT, DK, Mat{bXS, DS}, WgtNT{P + o.in_w + D * D, D, D},
-                    [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v + P[o.in_b + D + c]; });
-      gemm_tiles<0>(MT, NT, DK, Mat{bXS, DS}, WgtNT{P + o.in_w + 2 * D * D, D, D},
-                    [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v + P[o.in_b + 2 * D + c]; });
+      gemm_packed(MT, NT, DK, Mat{bQN, DS}, pk(i * 6 + 0, 0), P + o.in_b, D,
+                  [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v * qscale; });
+      gemm_packed(MT, NT, DK, Mat{bXS, DS}, pk(i * 6 + 1, 0), P + o.in_b + D, D,
+                  [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v; });
+      gemm_packed(MT, NT, DK, Mat{bXS, DS}, pk(i * 6 + 2, 0), P + o.in_b + 2 * D, D,
+                  [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v; });
       __syncthreads();
       tap(a, b, tb + 1, bQ, L, D, DS);
       tap(a, b, tb + 2, bK, L, D, DS);
@@ -210,20 +219,7 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
       // causal softmax (+ attention dropout); keys j > r get exact zeros up to LP
       {
         const DropSite dsA = drop_site(a.drop_on, seed, site_attn(i), seq, a.drop_thr, a.drop_scale);
-        for (int r = wave; r < L; r += nw) {
-          lds_f* row = bXS + r * SLD;
-          float m = -INFINITY;
-          for (int j = lane; j <= r; j += 64) m = fmaxf(m, row[j]);
-          m = wave_max(m);
-          float s = 0.f;
-          for (int j = lane; j <= r; j += 64) {
-            const float e = expf(row[j] - m);
-            row[j] = e;
-            s += e;
-          }
-          s = wave_sum(s);
-          for (int j = lane; j < LP; j += 64) row[j] = j <= r ? (row[j] / s) * drop_mul(dsA, r, j) : 0.f;
-        }
+        softmax_rows<true>(bXS, L, SLD, LP, dsA);
       }
       __syncthreads();
       tap(a, b, tb + 4, bXS, L, L, SLD);
@@ -231,9 +227,9 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
       gemm_tiles<2>(MT, NT, LP, Mat{bXS, SLD}, Mat{bV, DS}, [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v; });
       __syncthreads();
       // h1 = LN(x) + (o Wo^T + bo)
-      gemm_tiles<0>(MT, NT, DK, Mat{bQ, DS}, WgtNT{P + o.out_w, D, D}, [&](int r, int c, float v) {
+      gemm_packed(MT, NT, DK, Mat{bQ, DS}, pk(i * 6 + 3, 0), P + o.out_b, D, [&](int r, int c, float v) {
         if (c < D) {
-          const float h = bQN[r * DS + c] + (v + P[o.out_b + c]);
+          const float h = bQN[r * DS + c] + v;
           bXS[r * DS + c] = h;
           if (a.save_h1 && r < L) a.save_h1[((int64_t)i * B * L + rowbase + r) * D + c] = h;
         }
@@ -246,13 +242,13 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
       // PW-FFN: y = (drop2(relu(drop1(h2 W1^T + b1)) W2^T + b2) + h2) * keep
       const DropSite ds1 = drop_site(a.drop_on, seed, site_ffn1(i), seq, a.drop_thr, a.drop_scale);
       const DropSite ds2 = drop_site(a.drop_on, seed, site_ffn2(i), seq, a.drop_thr, a.drop_scale);
-      gemm_tiles<0>(MT, NT, DK, Mat{bQN, DS}, WgtNT{P + o.c1_w, D, D}, [&](int r, int c, float v) {
-        if (c < D) bQ[r * DS + c] = fmaxf((v + P[o.c1_b + c]) * drop_mul(ds1, r, c), 0.f);
+      gemm_packed(MT, NT, DK, Mat{bQN, DS}, pk(i * 6 + 4, 0), P + o.c1_b, D, [&](int r, int c, float v) {
+        if (c < D) bQ[r * DS + c] = fmaxf(v * drop_mul(ds1, r, c), 0.f);
       });
       __syncthreads();
-      gemm_tiles<0>(MT, NT, DK, Mat{bQ, DS}, WgtNT{P + o.c2_w, D, D}, [&](int r, int c, float v) {
+      gemm_packed(MT, NT, DK, Mat{bQ, DS}, pk(i * 6 + 5, 0), P + o.c2_b, D, [&](int r, int c, float v) {
         if (c < D) {
-          const float y = ((v + P[o.c2_b + c]) * drop_mul(ds2, r, c) + bQN[r * DS + c]) * s_keep[r];
+          const float y = (v * drop_mul(ds2, r, c) + bQN[r * DS + c]) * s_keep[r];
           bXS[r * DS + c] = y;
           if (a.save_x && r < L) a.save_x[((int64_t)(i + 1) * B * L + rowbase + r) * D + c] = y;
         }
@@ -264,8 +260,8 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
     // ---- head: (last_conv) -> last LayerNorm -> hidden, pos/neg logits, BCE partial sums
     const lds_f* hin = bXS;
     if (kind == SRFRD_SRFR) {
-      gemm_tiles<0>(MT, (di + 15) >> 4, DK, Mat{bXS, DS}, WgtNT{P + ly.off_lc_w, di, D},
-                    [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v + P[ly.off_lc_b + c]; });
+      gemm_packed(MT, (di + 15) >> 4, DK, Mat{bXS, DS}, pk(ly.n_blocks * 6, 0), P + ly.off_lc_b, di,
+                  [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v; });
       __syncthreads();
       hin = bQ;
     }
@@ -273,33 +269,36 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
     __syncthreads();
     {
       float sp = 0.f, sn = 0.f, cnt = 0.f;
-      for (int t = wave; t < L; t += nw) {
-        const float h = lane < dout ? bQN[t * DS + lane] : 0.f;
-        if (lane < dout) a.hidden[(rowbase + t) * dout + lane] = h;
-        float pl = 0.f, nl = 0.f;
-        if (a.pos_ids) {
-          const int pid = s_pid[t];
-          float e = 0.f;
-          if (lane < di) e = table[(int64_t)pid * di + lane];
-          else if (kind == SRFRD_SRFRN && lane < D) e = P[ly.off_side + (int)a.pos_fk[rowbase + t] * dfk + (lane - di)];
-          pl = wave_sum(h * e);
-          if (lane == 0) a.pos_logits[rowbase + t] = pl;
+      const int q = tid & 3;
+      const bool srfrn = kind == SRFRD_SRFRN;
+      for (int t = tid >> 2; t < L; t += nthr >> 2) {                  // one DPP quad per position
+        const int pid = s_pid[t], nid = s_nid[t];
+        const int pf = (srfrn && a.pos_ids) ? (int)a.pos_fk[rowbase + t] : 0;
+        const int nf = (srfrn && a.neg_ids) ? (int)a.neg_fk[rowbase + t] : 0;
+        float ap = 0.f, an = 0.f;
+#pragma unroll
+        for (int j = 0; j < kQC; ++j) {
+          const int c = q + 4 * j;
+          if (c < dout) {
+            const float h = bQN[t * DS + c];
+            a.hidden[(rowbase + t) * dout + c] = h;
+            if (a.pos_ids) ap += h * (c < di ? table[(int64_t)pid * di + c] : P[ly.off_side + pf * dfk + (c - di)]);
+            if (a.neg_ids) an += h * (c < di ? table[(int64_t)nid * di + c] : P[ly.off_side + nf * dfk + (c - di)]);
+          }
         }
-        if (a.neg_ids) {
-          const int nid = s_nid[t];
-          float e = 0.f;
-          if (lane < di) e = table[(int64_t)nid * di + lane];
-          else if (kind == SRFRD_SRFRN && lane < D) e = P[ly.off_side + (int)a.neg_fk[rowbase + t] * dfk + (lane - di)];
-          nl = wave_sum(h * e);
-          if (lane == 0) a.neg_logits[rowbase + t] = nl;
-        }
-        if (a.loss_part && s_pid[t] != 0) {      // trainer.py:36-38: both terms indexed by pos != 0
-          sp += softplus_f(-pl);
-          sn += softplus_f(nl);
-          cnt += 1.f;
+        const float pl = quad_sum(ap), nl = quad_sum(an);
+        if (q == 0) {
+          if (a.pos_ids) a.pos_logits[rowbase + t] = pl;
+          if (a.neg_ids) a.neg_logits[rowbase + t] = nl;
+          if (a.loss_part && pid != 0) {          // trainer.py:36-38: both terms indexed by pos != 0
+            sp += softplus_f(-pl);
+            sn += softplus_f(nl);
+            cnt += 1.f;
+          }
         }
       }
       if (a.loss_part) {
+        sp = wave_sum(sp); sn = wave_sum(sn); cnt = wave_sum(cnt);
         if (lane == 0) {
           s_misc[8 + wave * 3 + 0] = sp;
           s_misc[8 + wave * 3 + 1] = sn;
@@ -395,21 +394,13 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
   const float qscale = a.qscale;
   const uint32_t seed = a.seed_dev ? *a.seed_dev : a.seed;
   const int B = a.B;
+  // packed weight of matrix `mat` (block*6 + {Wq,Wk,Wv,Wo,W1,W2}; n_blocks*6 = last_conv); form 0: x W^T, 1: dy W
+  auto pk = [&](int mat, int form) {
+    return PackedB{reinterpret_cast<const float4*>(a.packed) + ((int64_t)mat * 2 + form) * (kPackFloats / 4)};
+  };
   float* slab = a.grad_slabs + (int64_t)blockIdx.x * ly.n_dense;
   for (int64_t i = tid; i < ly.n_dense; i += nthr) slab[i] = 0.f;
   __syncthreads();
-  auto slab_rmw = [&](int64_t off, int R, int C) {
-    return [=](int r, int c, float v) { if (r < R && c < C) slab[off + r * C + c] += v; };
-  };
-  // dW (R x C at off_w) and, through the ones column C of the B operand, db (R at off_b) in one epilogue
-  auto slab_rmw_wb = [&](int64_t off_w, int64_t off_b, int R, int C) {
-    return [=](int r, int c, float v) {
-      if (r < R) {
-        if (c < C) slab[off_w + r * C + c] += v;
-        else if (c == C) slab[off_b + r] += v;
-      }
-    };
-  };
   const bool fold_bias = (D & 15) != 0;       // a spare padded column exists in the last n-tile
   const float keep_scale = a.drop_on ? a.drop_scale : 1.0f;
 
@@ -417,6 +408,7 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const int64_t rowbase = (int64_t)b * L;
     const uint32_t seq = (uint32_t)(a.seq0 + b);
+    const int rmw = b != (int)blockIdx.x;      // first sequence of this workgroup: the slab is still all zero
     for (int t = tid; t < LP; t += nthr) {
       const bool in = t < L;
       const int id = in ? (int)a.in_ids[rowbase + t] : 0;
@@ -458,37 +450,51 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
 
     const lds_f* lnin = bX;
     if (kind == SRFRD_SRFR) {
-      gemm_tiles<0>(MT, (di + 15) >> 4, DK, Mat{bX, DS}, WgtNT{P + ly.off_lc_w, di, D},
-                    [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v + P[ly.off_lc_b + c]; });
+      gemm_packed(MT, (di + 15) >> 4, DK, Mat{bX, DS}, pk(ly.n_blocks * 6, 0), P + ly.off_lc_b, di,
+                  [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v; });
       __syncthreads();
       lnin = bQ;
     }
-    // ---- logits backward: dh, item-table scatter (float atomics; row 0 = padding_idx gets none)
-    for (int t = wave; t < L; t += nw) {
-      const float dp = s_dpl[t], dn = s_dnl[t];
-      const int pid = s_pid[t], nid = s_nid[t];
-      float h = 0.f, dh = 0.f;
-      if (lane < dout) {
-        h = a.c_hidden[(rowbase + t) * dout + lane];
-        if (a.d_hidden) dh = a.d_hidden[(rowbase + t) * dout + lane];
-      }
-      if (lane < di) {
-        if (a.pos_ids) {
-          dh += dp * table[(int64_t)pid * di + lane];
-          if (pid != 0 && dp != 0.f) atomicAdd(&a.grad_table[(int64_t)pid * di + lane], dp * h);
+    // ---- logits backward.  Pass 1 (one quad per position): dh -> bG, hidden rows staged in bT.
+    {
+      const int q = tid & 3;
+      const bool srfrn = kind == SRFRD_SRFRN;
+      for (int t = tid >> 2; t < L; t += nthr >> 2) {
+        const float dp = s_dpl[t], dn = s_dnl[t];
+        const int pid = s_pid[t], nid = s_nid[t], pf = s_pfk[t], nf = s_nfk[t];
+#pragma unroll
+        for (int j = 0; j < kQC; ++j) {
+          const int c = q + 4 * j;
+          if (c < D) {
+            float dh = 0.f;
+            if (c < dout) {
+              bT[t * DS + c] = a.c_hidden[(rowbase + t) * dout + c];
+              if (a.d_hidden) dh = a.d_hidden[(rowbase + t) * dout + c];
+              if (c < di) {
+                if (a.pos_ids) dh += dp * table[(int64_t)pid * di + c];
+                if (a.neg_ids) dh += dn * table[(int64_t)nid * di + c];
+              } else if (srfrn) {
+                if (a.pos_ids) dh += dp * P[ly.off_side + pf * dfk + (c - di)];
+                if (a.neg_ids) dh += dn * P[ly.off_side + nf * dfk + (c - di)];
+              }
+            }
+            bG[t * DS + c] = dh;
+          }
         }
-        if (a.neg_ids) {
-          dh += dn * table[(int64_t)nid * di + lane];
-          if (nid != 0 && dn != 0.f) atomicAdd(&a.grad_table[(int64_t)nid * di + lane], dn * h);
-        }
-      } else if (kind == SRFRD_SRFRN && lane < D) {
-        if (a.pos_ids) dh += dp * P[ly.off_side + s_pfk[t] * dfk + (lane - di)];
-        if (a.neg_ids) dh += dn * P[ly.off_side + s_nfk[t] * dfk + (lane - di)];
-        bT[t * DS + lane] = h;            // kept for the fake_embed gradient pass below
       }
-      if (lane < D) bG[t * DS + lane] = lane < dout ? dh : 0.f;
     }
     __syncthreads();
+    // Pass 2 (one wave per position, lane = channel): item-table scatter as whole 4*d_item-byte row segments, the
+    // access shape float atomics run at full rate for; row 0 (padding_idx) receives none.
+    for (int t = wave; t < L; t += nw) {
+      if (lane < di) {
+        const float h = bT[t * DS + lane];
+        const float dp = s_dpl[t], dn = s_dnl[t];
+        const int pid = s_pid[t], nid = s_nid[t];
+        if (a.pos_ids && pid != 0 && dp != 0.f) atomicAdd(&a.grad_table[(int64_t)pid * di + lane], dp * h);
+        if (a.neg_ids && nid != 0 && dn != 0.f) atomicAdd(&a.grad_table[(int64_t)nid * di + lane], dn * h);
+      }
+    }
     if (kind == SRFRD_SRFRN && wave == (1 % nw) && lane < dfk && (a.pos_ids || a.neg_ids)) {
       for (int f = 1; f <= 2; ++f) {      // fake_embed rows 1 (fake) and 2 (real); row 0 is padding_idx
         float s = 0.f;
@@ -499,17 +505,21 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
         slab[ly.off_side + f * dfk + lane] += s;
       }
     }
-    // ---- last LayerNorm backward (in place in bG)
-    {
-      float dg = 0.f, db = 0.f;
-      ln_bwd_rows<false>(bG, lnin, bG, L, DS, dout, P + ly.off_ll_w, dg, db);
-      ln_param_grads_to_slab(s_red, dg, db, dout, slab + ly.off_ll_w, slab + ly.off_ll_b);
-    }
+    // ---- last LayerNorm backward: dx -> bK, g * xhat -> bO; dgamma / dbeta as ones-row GEMMs on the matrix cores
+    ln_bwd_rows<false>(bG, lnin, bK, bO, L, LP, DS, dout, P + ly.off_ll_w);
+    __syncthreads();
+    gemm_tiles<0>(1, (dout + 15) >> 4, LP, OnesRow{}, Mat{bG, DS},
+                  [=](int r, int c, float v) { if (r == 0 && c < dout) slab[ly.off_ll_b + c] += v; });
+    gemm_tiles<0>(1, (dout + 15) >> 4, LP, OnesRow{}, Mat{bO, DS},
+                  [=](int r, int c, float v) { if (r == 0 && c < dout) slab[ly.off_ll_w + c] += v; });
+    __syncthreads();
+    { lds_f* t_ = bG; bG = bK; bK = t_; }
     if (kind == SRFRD_SRFR) {             // hc = hf Wlc^T + blc
-      gemm_tiles<0>((di + 15) >> 4, NT, LP, MatT{bG, DS}, Mat{bX, DS}, slab_rmw(ly.off_lc_w, di, D));
-      colsum_to_slab(0, bG, DS, L, di, slab + ly.off_lc_b);
-      gemm_tiles<0>(MT, NT, (di + 3) & ~3, Mat{bG, DS}, WgtNN{P + ly.off_lc_w, di, D},
-                    [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });
+      gemm_slab((di + 15) >> 4, NT, LP, MatT{bG, DS}, MatOnes{bX, DS, D},
+                SlabWB{slab + ly.off_lc_w, fold_bias ? slab + ly.off_lc_b : nullptr, di, D, rmw});
+      if (!fold_bias) colsum_to_slab(0, bG, DS, L, di, slab + ly.off_lc_b);
+      gemm_packed(MT, NT, (di + 3) & ~3, Mat{bG, DS}, pk(ly.n_blocks * 6, 1), nullptr, 0,
+                  [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });
       __syncthreads();
       lds_f* t_ = bG; bG = bT; bT = t_;
     }
@@ -536,32 +546,29 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
         bK[t * DS + c] = t < L ? bG[t * DS + c] * drop_mul(ds2, t, c) : 0.f;
       }
       __syncthreads();
-      gemm_tiles<0>(MT, NT, DK, Mat{bQN, DS}, WgtNT{P + o.c1_w, D, D}, [&](int r, int c, float v) {
-        if (c < D) bQ[r * DS + c] = fmaxf((v + P[o.c1_b + c]) * drop_mul(ds1, r, c), 0.f);   // r = relu(drop1(a1))
+      gemm_packed(MT, NT, DK, Mat{bQN, DS}, pk(i * 6 + 4, 0), P + o.c1_b, D, [&](int r, int c, float v) {
+        if (c < D) bQ[r * DS + c] = fmaxf(v * drop_mul(ds1, r, c), 0.f);                        // r = relu(drop1(a1))
       });
       __syncthreads();
-      if (fold_bias) gemm_tiles<0>(NT, NT, LP, MatT{bK, DS}, MatOnes{bQ, DS, D}, slab_rmw_wb(o.c2_w, o.c2_b, D, D));
-      else {
-        gemm_tiles<0>(NT, NT, LP, MatT{bK, DS}, Mat{bQ, DS}, slab_rmw(o.c2_w, D, D));         // dW2 += dA2^T r
-        colsum_to_slab(0, bK, DS, L, D, slab + o.c2_b);
-      }
-      gemm_tiles<0>(MT, NT, DK, Mat{bK, DS}, WgtNN{P + o.c2_w, D, D}, [&](int r, int c, float v) {
+      gemm_slab(NT, NT, LP, MatT{bK, DS}, MatOnes{bQ, DS, D},                                   // dW2 += dA2^T r (+ db2)
+                SlabWB{slab + o.c2_w, fold_bias ? slab + o.c2_b : nullptr, D, D, rmw});
+      if (!fold_bias) colsum_to_slab(0, bK, DS, L, D, slab + o.c2_b);
+      gemm_packed(MT, NT, DK, Mat{bK, DS}, pk(i * 6 + 5, 1), nullptr, 0, [&](int r, int c, float v) {
         if (c < D) bV[r * DS + c] = bQ[r * DS + c] > 0.f ? v * keep_scale : 0.f;               // dA1
       });
       __syncthreads();
-      if (fold_bias) gemm_tiles<0>(NT, NT, LP, MatT{bV, DS}, MatOnes{bQN, DS, D}, slab_rmw_wb(o.c1_w, o.c1_b, D, D));
-      else {
-        gemm_tiles<0>(NT, NT, LP, MatT{bV, DS}, Mat{bQN, DS}, slab_rmw(o.c1_w, D, D));        // dW1 += dA1^T h2
-        colsum_to_slab(1 % nw, bV, DS, L, D, slab + o.c1_b);
-      }
-      gemm_tiles<0>(MT, NT, DK, Mat{bV, DS}, WgtNN{P + o.c1_w, D, D},
-                    [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });           // dh2 = dy + dA1 W1
+      gemm_slab(NT, NT, LP, MatT{bV, DS}, MatOnes{bQN, DS, D},                                  // dW1 += dA1^T h2 (+ db1)
+                SlabWB{slab + o.c1_w, fold_bias ? slab + o.c1_b : nullptr, D, D, rmw});
+      if (!fold_bias) colsum_to_slab(1 % nw, bV, DS, L, D, slab + o.c1_b);
+      gemm_packed(MT, NT, DK, Mat{bV, DS}, pk(i * 6 + 4, 1), nullptr, 0,
+                  [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });             // dh2 = dy + dA1 W1
       __syncthreads();
-      {
-        float dg = 0.f, db = 0.f;
-        ln_bwd_rows<false>(bG, bX, bG, L, DS, D, P + o.ln2_w, dg, db);                         // dh1
-        ln_param_grads_to_slab(s_red, dg, db, D, slab + o.ln2_w, slab + o.ln2_b);
-      }
+      ln_bwd_rows<false>(bG, bX, bT, bV, L, LP, DS, D, P + o.ln2_w);                           // dh1 -> bT
+      __syncthreads();
+      gemm_tiles<0>(1, NT, LP, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln2_b + c] += v; });
+      gemm_tiles<0>(1, NT, LP, OnesRow{}, Mat{bV, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln2_w + c] += v; });
+      __syncthreads();
+      { lds_f* t_ = bG; bG = bT; bT = t_; }
       tap(a, b, tb + 0, bG, L, D, DS);
       // ================= attention half: h1 = LN1(x) + (P v) Wo^T + bo
       for (int idx = tid; idx < L * D; idx += nthr) {
@@ -571,62 +578,32 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
       __syncthreads();
       ln_rows(bX, bQN, L, DS, D, P + o.ln1_w, P + o.ln1_b);
       __syncthreads();
-      gemm_tiles<0>(MT, NT, DK, Mat{bQN, DS}, WgtNT{P + o.in_w, D, D},
-                    [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = (v + P[o.in_b + c]) * qscale; });
-      gemm_tiles<0>(MT, NT, DK, Mat{bX, DS}, WgtNT{P + o.in_w + D * D, D, D},
-                    [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v + P[o.in_b + D + c]; });
-      gemm_tiles<0>(MT, NT, DK, Mat{bX, DS}, WgtNT{P + o.in_w + 2 * D * D, D, D},
-                    [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v + P[o.in_b + 2 * D + c]; });
+      gemm_packed(MT, NT, DK, Mat{bQN, DS}, pk(i * 6 + 0, 0), P + o.in_b, D,
+                  [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v * qscale; });
+      gemm_packed(MT, NT, DK, Mat{bX, DS}, pk(i * 6 + 1, 0), P + o.in_b + D, D,
+                  [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v; });
+      gemm_packed(MT, NT, DK, Mat{bX, DS}, pk(i * 6 + 2, 0), P + o.in_b + 2 * D, D,
+                  [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v; });
       __syncthreads();
       gemm_tiles<1>(MT, MT, DK, Mat{bQ, DS}, MatT{bK, DS}, [&](int r, int c, float v) { S1[r * SLD + c] = v; });
       __syncthreads();
-      for (int r = wave; r < L; r += nw) {                       // P (dropout NOT folded in: applied on load)
-        lds_f* row = S1 + r * SLD;
-        float m = -INFINITY;
-        for (int j = lane; j <= r; j += 64) m = fmaxf(m, row[j]);
-        m = wave_max(m);
-        float s = 0.f;
-        for (int j = lane; j <= r; j += 64) {
-          const float e = expf(row[j] - m);
-          row[j] = e;
-          s += e;
-        }
-        s = wave_sum(s);
-        for (int j = lane; j < LP; j += 64) row[j] = j <= r ? row[j] / s : 0.f;
-      }
+      softmax_rows<false>(S1, L, SLD, LP, dsA);                  // P (dropout NOT folded in: applied on load)
       __syncthreads();
       gemm_tiles<2>(MT, NT, LP, MatDrop{S1, SLD, dsA}, Mat{bV, DS},
                     [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });            // o = drop(P) v
       __syncthreads();
-      if (fold_bias) gemm_tiles<0>(NT, NT, LP, MatT{bG, DS}, MatOnes{bO, DS, D}, slab_rmw_wb(o.out_w, o.out_b, D, D));
-      else {
-        gemm_tiles<0>(NT, NT, LP, MatT{bG, DS}, Mat{bO, DS}, slab_rmw(o.out_w, D, D));        // dWo += dh1^T o
-        colsum_to_slab(2 % nw, bG, DS, L, D, slab + o.out_b);
-      }
+      gemm_slab(NT, NT, LP, MatT{bG, DS}, MatOnes{bO, DS, D},                                   // dWo += dh1^T o (+ dbo)
+                SlabWB{slab + o.out_w, fold_bias ? slab + o.out_b : nullptr, D, D, rmw});
+      if (!fold_bias) colsum_to_slab(2 % nw, bG, DS, L, D, slab + o.out_b);
       __syncthreads();
-      gemm_tiles<0>(MT, NT, DK, Mat{bG, DS}, WgtNN{P + o.out_w, D, D},
-                    [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });            // do = dh1 Wo
+      gemm_packed(MT, NT, DK, Mat{bG, DS}, pk(i * 6 + 3, 1), nullptr, 0,
+                  [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });              // do = dh1 Wo
       __syncthreads();
       gemm_tiles<1>(MT, MT, DK, Mat{bO, DS}, MatT{bV, DS}, [&](int r, int c, float v) { S2[r * SLD + c] = v; });  // dPd = do v^T
       gemm_tiles<3>(MT, NT, LP, MatDropT{S1, SLD, dsA}, Mat{bO, DS},
                     [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });            // dv = drop(P)^T do
       __syncthreads();
-      for (int r = wave; r < LP; r += nw) {                      // dS = P * (dP - sum_j dP_j P_j), dP = mask * dPd
-        lds_f* drow = S2 + r * SLD;
-        if (r < L) {
-          const lds_f* prow = S1 + r * SLD;
-          float acc = 0.f;
-          for (int j = lane; j <= r; j += 64) {
-            const float dp = drow[j] * drop_mul(dsA, r, j);
-            drow[j] = dp;
-            acc += dp * prow[j];
-          }
-          acc = wave_sum(acc);
-          for (int j = lane; j < LP; j += 64) drow[j] = j <= r ? prow[j] * (drow[j] - acc) : 0.f;
-        } else {
-          for (int j = lane; j < LP; j += 64) drow[j] = 0.f;
-        }
-      }
+      softmax_bwd_rows(S2, S1, L, SLD, LP, dsA);                 // dS = P * (dP - sum_j dP_j P_j), dP = mask * dPd
       __syncthreads();
       lds_f* dKb = S1;                                           // P is dead: dk overlays it as [LP][DS]
       gemm_tiles<2>(MT, NT, LP, Mat{S2, SLD}, Mat{bK, DS},
@@ -634,30 +611,29 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
       gemm_tiles<3>(MT, NT, LP, MatT{S2, SLD}, Mat{bQ, DS},
                     [&](int r, int c, float v) { if (c < D) dKb[r * DS + c] = v; });           // dk = dS^T q
       __syncthreads();
-      if (fold_bias) {                                                                          // dWq, dWk, dWv (+ biases)
-        gemm_tiles<0>(NT, NT, LP, MatT{bO, DS}, MatOnes{bQN, DS, D}, slab_rmw_wb(o.in_w, o.in_b, D, D));
-        gemm_tiles<0>(NT, NT, LP, MatT{dKb, DS}, MatOnes{bX, DS, D}, slab_rmw_wb(o.in_w + D * D, o.in_b + D, D, D));
-        gemm_tiles<0>(NT, NT, LP, MatT{bT, DS}, MatOnes{bX, DS, D}, slab_rmw_wb(o.in_w + 2 * D * D, o.in_b + 2 * D, D, D));
-      } else {
-        gemm_tiles<0>(NT, NT, LP, MatT{bO, DS}, Mat{bQN, DS}, slab_rmw(o.in_w, D, D));
+      gemm_slab(NT, NT, LP, MatT{bO, DS}, MatOnes{bQN, DS, D},                                  // dWq (+ dbq)
+                SlabWB{slab + o.in_w, fold_bias ? slab + o.in_b : nullptr, D, D, rmw});
+      gemm_slab(NT, NT, LP, MatT{dKb, DS}, MatOnes{bX, DS, D},                                  // dWk (+ dbk)
+                SlabWB{slab + o.in_w + D * D, fold_bias ? slab + o.in_b + D : nullptr, D, D, rmw});
+      gemm_slab(NT, NT, LP, MatT{bT, DS}, MatOnes{bX, DS, D},                                   // dWv (+ dbv)
+                SlabWB{slab + o.in_w + 2 * D * D, fold_bias ? slab + o.in_b + 2 * D : nullptr, D, D, rmw});
+      if (!fold_bias) {
         colsum_to_slab(0, bO, DS, L, D, slab + o.in_b);
-        gemm_tiles<0>(NT, NT, LP, MatT{dKb, DS}, Mat{bX, DS}, slab_rmw(o.in_w + D * D, D, D));
         colsum_to_slab(1 % nw, dKb, DS, L, D, slab + o.in_b + D);
-        gemm_tiles<0>(NT, NT, LP, MatT{bT, DS}, Mat{bX, DS}, slab_rmw(o.in_w + 2 * D * D, D, D));
         colsum_to_slab(2 % nw, bT, DS, L, D, slab + o.in_b + 2 * D);
       }
-      gemm_tiles<0>(MT, NT, DK, Mat{bO, DS}, WgtNN{P + o.in_w, D, D},
-                    [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });           // dLN1 = dh1 + dq Wq
-      gemm_tiles<0>(MT, NT, DK, Mat{dKb, DS}, WgtNN{P + o.in_w + D * D, D, D},
-                    [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v; });            // dx  = dk Wk
-      gemm_tiles<0>(MT, NT, DK, Mat{bT, DS}, WgtNN{P + o.in_w + 2 * D * D, D, D},
-                    [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] += v; });           //     + dv Wv
+      gemm_packed(MT, NT, DK, Mat{bO, DS}, pk(i * 6 + 0, 1), nullptr, 0,
+                  [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });             // dLN1 = dh1 + dq Wq
+      gemm_packed(MT, NT, DK, Mat{dKb, DS}, pk(i * 6 + 1, 1), nullptr, 0,
+                  [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v; });              // dx  = dk Wk
+      gemm_packed(MT, NT, DK, Mat{bT, DS}, pk(i * 6 + 2, 1), nullptr, 0,
+                  [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] += v; });             //     + dv Wv
       __syncthreads();
-      {
-        float dg = 0.f, db = 0.f;
-        ln_bwd_rows<true>(bG, bX, bQ, L, DS, D, P + o.ln1_w, dg, db);                          //     + LN1 bwd
-        ln_param_grads_to_slab(s_red, dg, db, D, slab + o.ln1_w, slab + o.ln1_b);
-      }
+      ln_bwd_rows<true>(bG, bX, bQ, S2, L, LP, DS, D, P + o.ln1_w);                            //     + LN1 bwd
+      __syncthreads();
+      gemm_tiles<0>(1, NT, LP, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln1_b + c] += v; });
+      gemm_tiles<0>(1, NT, LP, OnesRow{}, Mat{S2, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln1_w + c] += v; });
+      __syncthreads();
       lds_f* t_ = bG; bG = bQ; bQ = t_;
       tap(a, b, tb + 1, bG, L, D, DS);
     }
@@ -696,6 +672,36 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
 }
 
 // ================================================================================================
+// weight packing: canonical (N, K) row-major weights -> MFMA B-fragment order, both product forms
+// ================================================================================================
+__global__ void __launch_bounds__(256) pack_weights_kernel(const srfrd_layout ly, const float* __restrict__ dense,
+                                                          float* __restrict__ packed) {
+  const int mf = blockIdx.x, mat = mf >> 1, form = mf & 1;
+  const int nb6 = ly.n_blocks * 6;
+  const float* W;
+  int N, K;
+  if (mat < nb6) {
+    const srfrd_block_off o = ly.blk[mat / 6];
+    const int m = mat % 6, D = ly.D;
+    W = dense + (m < 3 ? o.in_w + (int64_t)m * D * D : m == 3 ? o.out_w : m == 4 ? o.c1_w : o.c2_w);
+    N = K = D;
+  } else {
+    if (ly.off_lc_w < 0) return;
+    W = dense + ly.off_lc_w;
+    N = ly.d_item;
+    K = ly.D;
+  }
+  for (int idx = threadIdx.x; idx < kPackFloats; idx += blockDim.x) {
+    const int s = idx & 3, lane = (idx >> 2) & 63, kc = (idx >> 8) & 3, nt = idx >> 10;
+    const int k = kc * 16 + 4 * s + (lane >> 4), n = nt * 16 + (lane & 15);
+    float v;
+    if (form == 0) v = (n < N && k < K) ? W[n * K + k] : 0.f;      // B(k, n) = W[n][k]   (x W^T)
+    else v = (k < N && n < K) ? W[k * K + n] : 0.f;                // B(k, n) = W[k][n]   (dy W)
+    packed[(int64_t)mf * kPackFloats + idx] = v;
+  }
+}
+
+// ================================================================================================
 // host side
 // ================================================================================================
 static int g_num_cu = 0;
@@ -719,11 +725,11 @@ static int env_threads(const char* name, int dflt) {
   return (v >= 64 && v <= 512 && (v & 63) == 0) ? v : dflt;
 }
 
-static int fill_args(EncArgs& a, const srfrd_layout* lay, const float* item_table, const float* dense,
+static int fill_args(EncArgs& a, const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
                      const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids, const int64_t* pos_fake,
                      const int64_t* neg_ids, const int64_t* neg_fake, int B, int L, double dropout_p, uint32_t seed,
                      const uint32_t* seed_dev, int64_t seq_index0) {
-  if (!lay || !item_table || !dense || !input_ids || B <= 0 || L <= 0) return SRFRD_E_ARG;
+  if (!lay || !item_table || !dense || !packed || !input_ids || B <= 0 || L <= 0) return SRFRD_E_ARG;
   if (lay->D > SRFRD_MAX_D || lay->n_heads != 1 || lay->n_blocks > SRFRD_MAX_BLOCKS) return SRFRD_E_UNSUPPORTED;
   if (L > lay->max_len) return SRFRD_E_ARG;
   if (dropout_p < 0.0 || dropout_p >= 1.0) return SRFRD_E_ARG;
@@ -731,6 +737,7 @@ static int fill_args(EncArgs& a, const srfrd_layout* lay, const float* item_tabl
   a.lay = *lay;
   a.table = item_table;
   a.dense = dense;
+  a.packed = packed;
   a.in_ids = input_ids; a.fk_ids = fake_ids; a.pos_ids = pos_ids; a.pos_fk = pos_fake; a.neg_ids = neg_ids; a.neg_fk = neg_fake;
   a.B = B; a.L = L;
   a.seed = seed; a.seed_dev = seed_dev;
@@ -756,6 +763,19 @@ extern "C" int srfrd_lds_bytes(const srfrd_layout* lay, int L, int64_t* fwd_byte
   return 0;
 }
 
+extern "C" int64_t srfrd_packed_floats(const srfrd_layout* lay) {
+  if (!lay) return 0;
+  return (int64_t)(lay->n_blocks * 6 + 1) * 2 * kPackFloats;
+}
+
+extern "C" int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packed, void* stream) {
+  if (!lay || !dense || !packed) return SRFRD_E_ARG;
+  if (lay->D > SRFRD_MAX_D) return SRFRD_E_UNSUPPORTED;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((lay->n_blocks * 6 + 1) * 2), dim3(256), 0, (hipStream_t)stream, *lay, dense,
+                     packed);
+  return (int)hipGetLastError();
+}
+
 extern "C" int srfrd_bwd_grid(int B) {
   if (B <= 0) return SRFRD_E_ARG;
   const int cu = num_cu();
@@ -769,14 +789,14 @@ extern "C" int srfrd_debug_shape(const srfrd_layout* lay, int L, int64_t* slot_f
   return 0;
 }
 
-extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const float* dense,
+extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
                                  const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
                                  const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
                                  double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
                                  float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
                                  float* loss_part, float* dbg, int dbg_seq, void* stream) {
   EncArgs a = {};
-  int rc = fill_args(a, lay, item_table, dense, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
+  int rc = fill_args(a, lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
                      dropout_p, seed, seed_dev, seq_index0);
   if (rc) return rc;
   if (!hidden || (pos_ids && !pos_logits) || (neg_ids && !neg_logits)) return SRFRD_E_ARG;
@@ -801,7 +821,7 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
   return (int)hipGetLastError();
 }
 
-extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const float* dense,
+extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
                                  const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
                                  const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
                                  double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
@@ -810,7 +830,7 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_tabl
                                  const float* d_neg, int fused_bce, float* grad_table, float* grad_slabs, float* dbg,
                                  int dbg_seq, void* stream) {
   EncArgs a = {};
-  int rc = fill_args(a, lay, item_table, dense, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
+  int rc = fill_args(a, lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
                      dropout_p, seed, seed_dev, seq_index0);
   if (rc) return rc;
   if (!hidden || !save_x || !save_h1 || !grad_table || !grad_slabs) return SRFRD_E_ARG;

@@ -131,6 +131,7 @@ class _SRFRDBase(nn.Module):
         self._lay = None
         self._flat = None
         self._slots = None
+        self._packed = None
 
     # ---- layout / flat storage
     @property
@@ -198,6 +199,15 @@ class _SRFRDBase(nn.Module):
         assert covered == lay.n_table + lay.n_dense, "parameter list does not match the dense layout"
         self._flat, self._slots = flat, slots
 
+    def pack_weights(self):
+        """Refresh the MFMA-fragment-ordered copy of the encoder weights (srfrd_pack_weights) from the parameters."""
+        lay, flat = self.layout, self._flat
+        if self._packed is None or self._packed.device != flat.device:
+            self._packed = torch.empty(_lib.lib().srfrd_packed_floats(C.byref(lay)), device=flat.device, dtype=torch.float32)
+        check(_lib.lib().srfrd_pack_weights(C.byref(lay), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad),
+                                            ptr(self._packed), _stream()), "srfrd_pack_weights")
+        return self._packed
+
     # ---- launches
     def _launch_fwd(self, inp, fk, pos, pfk, neg, nfk, dropout_p, seed, save, seq0=0, dbg=None, dbg_seq=0):
         lay, flat = self.layout, self._flat
@@ -208,8 +218,9 @@ class _SRFRDBase(nn.Module):
         nl = torch.empty(B, L, device=dev, dtype=torch.float32) if neg is not None else None
         sx = torch.empty(lay.n_blocks + 1, B, L, lay.D, device=dev, dtype=torch.float32) if save else None
         sh = torch.empty(lay.n_blocks, B, L, lay.D, device=dev, dtype=torch.float32) if save else None
+        packed = self.pack_weights()          # parameters may have been stepped since the last call
         check(_lib.lib().srfrd_encoder_fwd(
-            C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad),
+            C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(packed),
             ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
             None, int(seq0), ptr(hidden), ptr(pl), ptr(nl), ptr(sx), ptr(sh), None, ptr(dbg), int(dbg_seq), _stream()),
             "srfrd_encoder_fwd")
@@ -224,7 +235,7 @@ class _SRFRDBase(nn.Module):
         n_slabs = _lib.lib().srfrd_bwd_grid(B)
         slabs = torch.empty(n_slabs, lay.n_dense, device=dev, dtype=torch.float32)
         check(_lib.lib().srfrd_encoder_bwd(
-            C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad),
+            C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(self._packed),
             ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
             None, int(seq0), ptr(out["hidden"]), ptr(out["pos_logits"]), ptr(out["neg_logits"]), ptr(out["save_x"]),
             ptr(out["save_h1"]), ptr(d_hidden), ptr(d_pl), ptr(d_nl), 0, ptr(gflat), ptr(slabs), ptr(dbg), int(dbg_seq),
