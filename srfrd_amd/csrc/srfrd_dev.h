@@ -46,12 +46,36 @@ __host__ __device__ __forceinline__ Geom make_geom(int L, int D) {
 
 __host__ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
-// LDS floats: forward = XS + 4 matrices; backward = 8 matrices + 2 score matrices; + slack + per-row scalars
-__host__ __device__ __forceinline__ int64_t fwd_lds_floats(const Geom& g) {
-  return (int64_t)imax(g.LP * g.DS, g.LP * g.SLD) + 4ll * g.LP * g.DS + kSlack + 4ll * g.LP + 64;
+// Compact, all-int32 view of srfrd_layout passed to the kernels (the full descriptor with its 8 x 12 int64 block
+// table costs hundreds of SGPRs; block offsets are affine in the block index, so they are recomputed instead).
+struct Dims {
+  int kind, d_item, d_fake, D, d_out, n_labels, n_blocks;
+  int off_pos, off_side, blk0, blk_stride, off_lc_w, off_lc_b, off_ll_w, off_ll_b, n_dense;
+};
+struct BlkOff {
+  int ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, c1_w, c1_b, c2_w, c2_b;
+};
+__host__ __device__ __forceinline__ BlkOff blk_off(int base, int D) {
+  const int DD = D * D;
+  BlkOff o;
+  o.ln1_w = base;          o.ln1_b = o.ln1_w + D;
+  o.in_w = o.ln1_b + D;    o.in_b = o.in_w + 3 * DD;
+  o.out_w = o.in_b + 3 * D; o.out_b = o.out_w + DD;
+  o.ln2_w = o.out_b + D;   o.ln2_b = o.ln2_w + D;
+  o.c1_w = o.ln2_b + D;    o.c1_b = o.c1_w + DD;
+  o.c2_w = o.c1_b + D;     o.c2_b = o.c2_w + DD;
+  return o;
 }
-__host__ __device__ __forceinline__ int64_t bwd_lds_floats(const Geom& g) {
-  return 8ll * g.LP * g.DS + 2ll * imax(g.LP * g.SLD, g.LP * g.DS) + kSlack + 10ll * g.LP + 64 + 8ll * 2 * 64;
+__host__ __device__ __forceinline__ int blk_stride_of(int D) { return 10 * D + 6 * D * D; }
+// LDS cache of the LayerNorm parameters: vector v of block i at (4 i + v) * 64, the last LayerNorm's two after them
+__host__ __device__ __forceinline__ int ln_cache_floats(int n_blocks) { return (4 * n_blocks + 2) * 64; }
+
+// LDS floats: forward = XS + 4 matrices; backward = 8 matrices + 2 score matrices; + slack + per-row scalars
+__host__ __device__ __forceinline__ int64_t fwd_lds_floats(const Geom& g, int n_blocks) {
+  return (int64_t)imax(g.LP * g.DS, g.LP * g.SLD) + 4ll * g.LP * g.DS + kSlack + 4ll * g.LP + 64 + ln_cache_floats(n_blocks);
+}
+__host__ __device__ __forceinline__ int64_t bwd_lds_floats(const Geom& g, int n_blocks) {
+  return 8ll * g.LP * g.DS + 2ll * imax(g.LP * g.SLD, g.LP * g.DS) + kSlack + 10ll * g.LP + 64 + ln_cache_floats(n_blocks);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -156,30 +180,45 @@ struct SlabWB {
 template <int G, class AL, class BL>
 __device__ __forceinline__ void mma_group(f32x4 (&acc)[G], const AL& a, const BL& b, int mrow, int mstride, int ncol,
                                           int k0, int k1, int lq) {
-  int k = k0;
-  for (; k + 16 <= k1; k += 16) {
+  const int nfull = (k1 - k0) >> 4;      // full 16-deep chunks; the fragments of chunk c+1 are requested before the
+  if (nfull > 0) {                       // MFMAs of chunk c are issued (double buffering), so LDS latency is hidden
     float bv[4], av[4][G];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bv[s] = b(k + 4 * s + lq, ncol);
+    for (int s = 0; s < 4; ++s) {
+      bv[s] = b(k0 + 4 * s + lq, ncol);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int j = 0; j < G; ++j) av[s][j] = a(mrow + j * mstride, k0 + 4 * s + lq);
+    }
+    for (int c = 0; c < nfull; ++c) {
+      const int kn = k0 + (min(c + 1, nfull - 1) << 4);     // the last pass re-reads its own chunk (harmless)
+      float bn[4], an[4][G];
 #pragma unroll
-      for (int j = 0; j < G; ++j) av[s][j] = a(mrow + j * mstride, k + 4 * s + lq);
-    // keep all 4 + 4G loads in flight ahead of the MFMAs (hipcc otherwise re-serialises load -> wait -> mfma)
-    __builtin_amdgcn_sched_barrier(0);
+      for (int s = 0; s < 4; ++s) {
+        bn[s] = b(kn + 4 * s + lq, ncol);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < G; ++j) an[s][j] = a(mrow + j * mstride, kn + 4 * s + lq);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][j], bv[s], acc[j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][j], bv[s], acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bv[s] = bn[s];
+#pragma unroll
+        for (int j = 0; j < G; ++j) av[s][j] = an[s][j];
+      }
+    }
   }
-  for (; k < k1; k += 4) {
-    const float bv = b(k + lq, ncol);
-    float av[G];
+  for (int k = k0 + (nfull << 4); k < k1; k += 4) {
+    const float bt = b(k + lq, ncol);
+    float at[G];
 #pragma unroll
-    for (int j = 0; j < G; ++j) av[j] = a(mrow + j * mstride, k + lq);
+    for (int j = 0; j < G; ++j) at[j] = a(mrow + j * mstride, k + lq);
 #pragma unroll
-    for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv, acc[j], 0, 0, 0);
+    for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[j], bt, acc[j], 0, 0, 0);
   }
 }
 
@@ -251,79 +290,91 @@ __device__ __forceinline__ void gemm_slab(int m_tiles, int n_tiles, int k_end, A
   }
 }
 
-// packed-weight variant: C = A * Bpacked (+ bias[col]); k_end <= 64 and a multiple of 4
+// Weight fragments of the strip this wave owns in a packed GEMM, requested ahead of use (one phase early where the
+// call site allows) so that the L2 latency of the weights never sits on the critical path.
+struct WFrag {
+  float4 q[kPackKC];
+  float bias;
+};
+__device__ __forceinline__ WFrag load_wfrag(PackedB b, const float* bias, int nbias, int n_tiles) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nt = wave % n_tiles;
+  WFrag f;
+#pragma unroll
+  for (int kc = 0; kc < kPackKC; ++kc) f.q[kc] = b.chunk(nt, kc, lane);
+  const int c = (nt << 4) + (lane & 15);
+  f.bias = (bias != nullptr && c < nbias) ? bias[c] : 0.f;
+  return f;
+}
+
+// packed-weight GEMM: C = A * Bpacked (+ bias[col]); k_end <= 64.  k runs over whole 16-deep chunks: the packed
+// weights are zero beyond K, and A over-reads stay inside LDS on finite data, so the tail needs no predication.
 template <int G, class AL, class EPI>
-__device__ __forceinline__ void gemm_group_packed(int mt, int mgroups, int nt, int k_end, const AL& a, const PackedB& b,
-                                                  const float* bias, int nbias, const EPI& epi, int lane) {
+__device__ __forceinline__ void gemm_group_packed(int mt, int mgroups, int nt, int nchunks, const AL& a, const WFrag& w,
+                                                  const EPI& epi, int lane) {
   const int li = lane & 15, lq = lane >> 4;
   const int n0 = nt << 4;
-  float4 bq[kPackKC];
-#pragma unroll
-  for (int kc = 0; kc < kPackKC; ++kc) bq[kc] = b.chunk(nt, kc, lane);
-  const float bias_v = (bias != nullptr && n0 + li < nbias) ? bias[n0 + li] : 0.f;
   f32x4 acc[G];
 #pragma unroll
   for (int j = 0; j < G; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int mrow = (mt << 4) + li, mstride = mgroups << 4;
+  float av[4][G];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < G; ++j) av[s][j] = a(mrow + j * mstride, 4 * s + lq);
 #pragma unroll
   for (int kc = 0; kc < kPackKC; ++kc) {
-    const int kb = kc << 4;
-    if (kb + 16 <= k_end) {
-      float av[4][G];
+    if (kc < nchunks) {
+      const int kn = min(kc + 1, nchunks - 1) << 4;
+      float an[4][G];
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int j = 0; j < G; ++j) av[s][j] = a(mrow + j * mstride, kb + 4 * s + lq);
+        for (int j = 0; j < G; ++j) an[s][j] = a(mrow + j * mstride, kn + 4 * s + lq);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][j], bq[kc][s], acc[j], 0, 0, 0);
+        for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][j], w.q[kc][s], acc[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-    } else if (kb < k_end) {
-      const int nst = (k_end - kb) >> 2;     // 1..3 tail steps
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
-        if (s < nst) {
-          float av[G];
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int j = 0; j < G; ++j) av[j] = a(mrow + j * mstride, kb + 4 * s + lq);
-#pragma unroll
-          for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[kc][s], acc[j], 0, 0, 0);
-        }
+        for (int j = 0; j < G; ++j) av[s][j] = an[s][j];
     }
   }
 #pragma unroll
   for (int j = 0; j < G; ++j) {
     const int r0 = ((mt + j * mgroups) << 4) + (lq << 2), c = n0 + li;
-    epi(r0 + 0, c, acc[j][0] + bias_v);
-    epi(r0 + 1, c, acc[j][1] + bias_v);
-    epi(r0 + 2, c, acc[j][2] + bias_v);
-    epi(r0 + 3, c, acc[j][3] + bias_v);
+    epi(r0 + 0, c, acc[j][0] + w.bias);
+    epi(r0 + 1, c, acc[j][1] + w.bias);
+    epi(r0 + 2, c, acc[j][2] + w.bias);
+    epi(r0 + 3, c, acc[j][3] + w.bias);
   }
 }
 
+// n_tiles <= number of waves (every wave owns at most one strip: the one load_wfrag fetched for it)
 template <class AL, class EPI>
-__device__ __forceinline__ void gemm_packed(int m_tiles, int n_tiles, int k_end, AL a, PackedB b, const float* bias, int nbias,
-                                            EPI epi) {
+__device__ __forceinline__ void gemm_packed(int m_tiles, int n_tiles, int k_end, AL a, const WFrag& w, EPI epi) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
   const int mgroups = nw > n_tiles ? nw / n_tiles : 1;
-  const int units = n_tiles * mgroups;
-  for (int u = wave; u < units; u += nw) {
-    const int nt = u % n_tiles, g = u / n_tiles;
-    int mt = g;
-    while (mt + 3 * mgroups < m_tiles) {
-      gemm_group_packed<4>(mt, mgroups, nt, k_end, a, b, bias, nbias, epi, lane);
-      mt += 4 * mgroups;
-    }
-    if (mt + mgroups < m_tiles) {
-      gemm_group_packed<2>(mt, mgroups, nt, k_end, a, b, bias, nbias, epi, lane);
-      mt += 2 * mgroups;
-    }
-    if (mt < m_tiles) gemm_group_packed<1>(mt, mgroups, nt, k_end, a, b, bias, nbias, epi, lane);
+  if (wave >= n_tiles * mgroups) return;
+  const int nt = wave % n_tiles, g = wave / n_tiles;
+  const int nchunks = (k_end + 15) >> 4;
+  int mt = g;
+  while (mt + 3 * mgroups < m_tiles) {
+    gemm_group_packed<4>(mt, mgroups, nt, nchunks, a, w, epi, lane);
+    mt += 4 * mgroups;
   }
+  if (mt + mgroups < m_tiles) {
+    gemm_group_packed<2>(mt, mgroups, nt, nchunks, a, w, epi, lane);
+    mt += 2 * mgroups;
+  }
+  if (mt < m_tiles) gemm_group_packed<1>(mt, mgroups, nt, nchunks, a, w, epi, lane);
 }
 
 template <int TRI, class AL, class BL, class EPI>
@@ -370,8 +421,8 @@ __device__ __forceinline__ float quad_max(float v) {
 constexpr int kQC = SRFRD_MAX_D / 4;    // columns per lane of a quad (D <= 64)
 
 // Y[r] = LayerNorm(X[r]) for r < rows   (biased variance, eps inside the sqrt: torch.nn.LayerNorm)
-__device__ __forceinline__ void ln_rows(const lds_f* X, lds_f* Y, int rows, int ld, int D, const float* w,
-                                        const float* bia) {
+__device__ __forceinline__ void ln_rows(const lds_f* X, lds_f* Y, int rows, int ld, int D, const lds_f* w,
+                                        const lds_f* bia) {
   const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
   const float invD = 1.0f / (float)D;
   float wl[kQC], bl[kQC];
@@ -413,7 +464,7 @@ __device__ __forceinline__ void ln_rows(const lds_f* X, lds_f* Y, int rows, int 
 //   caller (ones-row GEMM), so this pass needs no cross-row reduction.
 template <bool ACCUM>
 __device__ __forceinline__ void ln_bwd_rows(const lds_f* GY, const lds_f* X, lds_f* OUT, lds_f* GXH, int rows, int LP, int ld,
-                                            int D, const float* w) {
+                                            int D, const lds_f* w) {
   const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
   for (int i = threadIdx.x; i < (LP - rows) * ld; i += blockDim.x) GXH[rows * ld + i] = 0.f;   // padding rows feed a k-sum
   const float invD = 1.0f / (float)D;
@@ -470,28 +521,40 @@ struct OnesRow {        // A operand whose row 0 is all ones (rows 1..15 zero): 
 
 // causal softmax of score rows r < rows in place; keys j > r get exact zeros up to LP.  MASKED folds the attention
 // dropout multiplier into the stored probabilities (forward); the backward keeps P unmasked and masks on load.
+// A quad owns a row; each lane keeps its (up to kSMJ) elements in registers, so the row is read once and written
+// once and the loops are fully unrolled (no per-element LDS round trip on the dependency chain).
+constexpr int kSMJ = 32;     // elements per lane: rows up to 128 keys
 template <bool MASKED>
 __device__ __forceinline__ void softmax_rows(lds_f* S, int rows, int sld, int LP, const DropSite& ds) {
   const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
+  const int nj = LP >> 2;                       // elements per lane (LP is a multiple of 16)
   for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
     lds_f* row = S + r * sld;
+    float x[kSMJ];
     float m = -INFINITY;
-    for (int j = q; j <= r; j += 4) m = fmaxf(m, row[j]);
+#pragma unroll
+    for (int i = 0; i < kSMJ; ++i) {
+      const int j = q + 4 * i;
+      x[i] = (i < nj && j <= r) ? row[j] : -INFINITY;
+      m = fmaxf(m, x[i]);
+    }
     m = quad_max(m);
     float s = 0.f;
-    for (int j = q; j <= r; j += 4) {
-      const float e = expf(row[j] - m);
-      row[j] = e;
-      s += e;
+#pragma unroll
+    for (int i = 0; i < kSMJ; ++i) {
+      const int j = q + 4 * i;
+      x[i] = (i < nj && j <= r) ? __expf(x[i] - m) : 0.f;      // v_exp_f32 path: ~1e-7 relative, far inside the 1e-4 bar
+      s += x[i];
     }
     s = quad_sum(s);
-    for (int j = q; j < LP; j += 4) {
-      float p = 0.f;
-      if (j <= r) {
-        p = row[j] / s;
+#pragma unroll
+    for (int i = 0; i < kSMJ; ++i) {
+      const int j = q + 4 * i;
+      if (i < nj) {
+        float p = x[i] / s;                      // exact zero above the diagonal (x = 0)
         if (MASKED) p *= drop_mul(ds, r, j);
+        row[j] = p;
       }
-      row[j] = p;
     }
   }
 }
@@ -499,20 +562,26 @@ __device__ __forceinline__ void softmax_rows(lds_f* S, int rows, int sld, int LP
 // dS = P * (dP - sum_j dP_j P_j), dP = mask * dPd, in place in dPd; rows >= rows (padding) are zeroed up to LP rows
 __device__ __forceinline__ void softmax_bwd_rows(lds_f* dPd, const lds_f* P, int rows, int sld, int LP, const DropSite& ds) {
   const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
+  const int nj = LP >> 2;
   for (int r = threadIdx.x >> 2; r < LP; r += rpp) {
     lds_f* drow = dPd + r * sld;
-    if (r < rows) {
-      const lds_f* prow = P + r * sld;
-      float acc = 0.f;
-      for (int j = q; j <= r; j += 4) {
-        const float dp = drow[j] * drop_mul(ds, r, j);
-        drow[j] = dp;
-        acc += dp * prow[j];
-      }
-      acc = quad_sum(acc);
-      for (int j = q; j < LP; j += 4) drow[j] = j <= r ? prow[j] * (drow[j] - acc) : 0.f;
-    } else {
-      for (int j = q; j < LP; j += 4) drow[j] = 0.f;
+    const lds_f* prow = P + r * sld;
+    float dp[kSMJ], p[kSMJ];
+    float acc = 0.f;
+    const bool live = r < rows;
+#pragma unroll
+    for (int i = 0; i < kSMJ; ++i) {
+      const int j = q + 4 * i;
+      const bool on = live && i < nj && j <= r;
+      p[i] = on ? prow[j] : 0.f;
+      dp[i] = on ? drow[j] * drop_mul(ds, r, j) : 0.f;
+      acc += dp[i] * p[i];
+    }
+    acc = quad_sum(acc);
+#pragma unroll
+    for (int i = 0; i < kSMJ; ++i) {
+      const int j = q + 4 * i;
+      if (i < nj) drow[j] = p[i] * (dp[i] - acc);
     }
   }
 }

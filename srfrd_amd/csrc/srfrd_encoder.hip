@@ -12,7 +12,7 @@
 namespace srfrd {
 
 struct EncArgs {
-  srfrd_layout lay;
+  Dims dm;
   const float* table;
   const float* dense;
   const float* packed;      // srfrd_pack_weights output (MFMA-fragment-ordered weights)
@@ -62,6 +62,24 @@ __device__ __forceinline__ void launder(float*& p) {
 #define STAMP(id) do {} while (0)
 #endif
 
+// LayerNorm weights / biases -> LDS once per workgroup (read by every row pass of every sequence)
+__device__ __forceinline__ void fill_ln_cache(lds_f* s_ln, const float* P, const Dims& ly) {
+  const int D = ly.D;
+  for (int idx = threadIdx.x; idx < (4 * ly.n_blocks + 2) * 64; idx += blockDim.x) {
+    const int vec = idx >> 6, c = idx & 63;
+    float v = 0.f;
+    if (vec < 4 * ly.n_blocks) {
+      const BlkOff o = blk_off(ly.blk0 + (vec >> 2) * ly.blk_stride, D);
+      const int sel = vec & 3;
+      const int off = sel == 0 ? o.ln1_w : sel == 1 ? o.ln1_b : sel == 2 ? o.ln2_w : o.ln2_b;
+      if (c < D) v = P[off + c];
+    } else if (c < ly.d_out) {
+      v = P[(vec == 4 * ly.n_blocks ? ly.off_ll_w : ly.off_ll_b) + c];
+    }
+    s_ln[idx] = v;
+  }
+}
+
 __device__ __forceinline__ void tap(const EncArgs& a, int b, int slot, const lds_f* buf, int rows, int cols, int ld) {
 #ifdef SRFRD_STAMPS
   return;
@@ -105,7 +123,7 @@ __device__ __forceinline__ int user_label_wave(int kind, const int64_t* fk_row, 
 // ================================================================================================
 __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const srfrd_layout& ly = a.lay;
+  const Dims& ly = a.dm;
   const Geom g = make_geom(a.L, ly.D);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6, nthr = blockDim.x;
   const int L = g.L, LP = g.LP, D = g.D, DS = g.DS, SLD = g.SLD, NT = g.NT, MT = g.MT, DK = g.DK;
@@ -122,11 +140,13 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
   lds_i* s_pid = (lds_i*)(tail + 2 * LP);
   lds_i* s_nid = (lds_i*)(tail + 3 * LP);
   lds_f* s_misc = tail + 4 * LP;          // 64 floats
+  lds_f* s_ln = s_misc + 64;              // LayerNorm parameter cache
   {
-    const int total = (int)fwd_lds_floats(g);
+    const int total = (int)fwd_lds_floats(g, ly.n_blocks);
     for (int i = tid; i < total; i += nthr) lds0[i] = 0.f;
   }
   __syncthreads();
+  fill_ln_cache(s_ln, a.dense, ly);
 
   const float* P = a.dense;
   const float* table = a.table;
@@ -196,19 +216,22 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
     tap(a, b, 0, bXS, L, D, DS);
 
     for (int i = 0; i < ly.n_blocks; ++i) {
-      const srfrd_block_off o = ly.blk[i];
+      const BlkOff o = blk_off(ly.blk0 + i * ly.blk_stride, D);
       const int tb = 1 + 8 * i;
       launder(bXS); launder(bQN); launder(bQ); launder(bK); launder(bV);
-      ln_rows(bXS, bQN, L, DS, D, P + o.ln1_w, P + o.ln1_b);
+      // weight fragments are requested one phase ahead of the GEMM that consumes them
+      const WFrag wq = load_wfrag(pk(i * 6 + 0, 0), P + o.in_b, D, NT);
+      const WFrag wk = load_wfrag(pk(i * 6 + 1, 0), P + o.in_b + D, D, NT);
+      const WFrag wv = load_wfrag(pk(i * 6 + 2, 0), P + o.in_b + 2 * D, D, NT);
+      ln_rows(bXS, bQN, L, DS, D, s_ln + (4 * i + 0) * 64, s_ln + (4 * i + 1) * 64);
       __syncthreads();
       tap(a, b, tb + 0, bQN, L, D, DS);
       // q = (LN(x) Wq^T + bq) * sqrt(1/d_h);  k = x Wk^T + bk;  v = x Wv^T + bv
-      gemm_packed(MT, NT, DK, Mat{bQN, DS}, pk(i * 6 + 0, 0), P + o.in_b, D,
-                  [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v * qscale; });
-      gemm_packed(MT, NT, DK, Mat{bXS, DS}, pk(i * 6 + 1, 0), P + o.in_b + D, D,
-                  [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v; });
-      gemm_packed(MT, NT, DK, Mat{bXS, DS}, pk(i * 6 + 2, 0), P + o.in_b + 2 * D, D,
-                  [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v; });
+      gemm_packed(MT, NT, DK, Mat{bQN, DS}, wq, [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v * qscale; });
+      gemm_packed(MT, NT, DK, Mat{bXS, DS}, wk, [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v; });
+      gemm_packed(MT, NT, DK, Mat{bXS, DS}, wv, [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v; });
+      const WFrag wo = load_wfrag(pk(i * 6 + 3, 0), P + o.out_b, D, NT);
+      const WFrag w1 = load_wfrag(pk(i * 6 + 4, 0), P + o.c1_b, D, NT);
       __syncthreads();
       tap(a, b, tb + 1, bQ, L, D, DS);
       tap(a, b, tb + 2, bK, L, D, DS);
@@ -227,7 +250,7 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
       gemm_tiles<2>(MT, NT, LP, Mat{bXS, SLD}, Mat{bV, DS}, [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v; });
       __syncthreads();
       // h1 = LN(x) + (o Wo^T + bo)
-      gemm_packed(MT, NT, DK, Mat{bQ, DS}, pk(i * 6 + 3, 0), P + o.out_b, D, [&](int r, int c, float v) {
+      gemm_packed(MT, NT, DK, Mat{bQ, DS}, wo, [&](int r, int c, float v) {
         if (c < D) {
           const float h = bQN[r * DS + c] + v;
           bXS[r * DS + c] = h;
@@ -236,17 +259,18 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
       });
       __syncthreads();
       tap(a, b, tb + 5, bXS, L, D, DS);
-      ln_rows(bXS, bQN, L, DS, D, P + o.ln2_w, P + o.ln2_b);
+      ln_rows(bXS, bQN, L, DS, D, s_ln + (4 * i + 2) * 64, s_ln + (4 * i + 3) * 64);
       __syncthreads();
       tap(a, b, tb + 6, bQN, L, D, DS);
       // PW-FFN: y = (drop2(relu(drop1(h2 W1^T + b1)) W2^T + b2) + h2) * keep
       const DropSite ds1 = drop_site(a.drop_on, seed, site_ffn1(i), seq, a.drop_thr, a.drop_scale);
       const DropSite ds2 = drop_site(a.drop_on, seed, site_ffn2(i), seq, a.drop_thr, a.drop_scale);
-      gemm_packed(MT, NT, DK, Mat{bQN, DS}, pk(i * 6 + 4, 0), P + o.c1_b, D, [&](int r, int c, float v) {
+      const WFrag w2 = load_wfrag(pk(i * 6 + 5, 0), P + o.c2_b, D, NT);
+      gemm_packed(MT, NT, DK, Mat{bQN, DS}, w1, [&](int r, int c, float v) {
         if (c < D) bQ[r * DS + c] = fmaxf(v * drop_mul(ds1, r, c), 0.f);
       });
       __syncthreads();
-      gemm_packed(MT, NT, DK, Mat{bQ, DS}, pk(i * 6 + 5, 0), P + o.c2_b, D, [&](int r, int c, float v) {
+      gemm_packed(MT, NT, DK, Mat{bQ, DS}, w2, [&](int r, int c, float v) {
         if (c < D) {
           const float y = (v * drop_mul(ds2, r, c) + bQN[r * DS + c]) * s_keep[r];
           bXS[r * DS + c] = y;
@@ -260,12 +284,12 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const EncArgs a) {
     // ---- head: (last_conv) -> last LayerNorm -> hidden, pos/neg logits, BCE partial sums
     const lds_f* hin = bXS;
     if (kind == SRFRD_SRFR) {
-      gemm_packed(MT, (di + 15) >> 4, DK, Mat{bXS, DS}, pk(ly.n_blocks * 6, 0), P + ly.off_lc_b, di,
-                  [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v; });
+      const WFrag wl = load_wfrag(pk(ly.n_blocks * 6, 0), P + ly.off_lc_b, di, (di + 15) >> 4);
+      gemm_packed(MT, (di + 15) >> 4, DK, Mat{bXS, DS}, wl, [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v; });
       __syncthreads();
       hin = bQ;
     }
-    ln_rows(hin, bQN, L, DS, dout, P + ly.off_ll_w, P + ly.off_ll_b);
+    ln_rows(hin, bQN, L, DS, dout, s_ln + (4 * ly.n_blocks) * 64, s_ln + (4 * ly.n_blocks + 1) * 64);
     __syncthreads();
     {
       float sp = 0.f, sn = 0.f, cnt = 0.f;
@@ -351,7 +375,7 @@ __device__ __forceinline__ void ln_param_grads_to_slab(lds_f* s_red, float dg, f
 
 __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const srfrd_layout& ly = a.lay;
+  const Dims& ly = a.dm;
   const Geom g = make_geom(a.L, ly.D);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6, nthr = blockDim.x;
   const int L = g.L, LP = g.LP, D = g.D, DS = g.DS, SLD = g.SLD, NT = g.NT, MT = g.MT, DK = g.DK;
@@ -378,11 +402,13 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
   lds_f* s_dpl = tail + 7 * LP;
   lds_f* s_dnl = tail + 8 * LP;
   lds_f* s_misc = tail + 10 * LP;        // 64
-  lds_f* s_red = s_misc + 64;            // 8 waves x 2 x 64
+  lds_f* s_ln = s_misc + 64;             // LayerNorm parameter cache
   {
-    const int total = (int)bwd_lds_floats(g);
+    const int total = (int)bwd_lds_floats(g, ly.n_blocks);
     for (int i = tid; i < total; i += nthr) lds0[i] = 0.f;
   }
+  __syncthreads();
+  fill_ln_cache(s_ln, a.dense, ly);
   const float* P = a.dense;
   const float* table = a.table;
   const int kind = ly.kind;
@@ -450,8 +476,8 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
 
     const lds_f* lnin = bX;
     if (kind == SRFRD_SRFR) {
-      gemm_packed(MT, (di + 15) >> 4, DK, Mat{bX, DS}, pk(ly.n_blocks * 6, 0), P + ly.off_lc_b, di,
-                  [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v; });
+      const WFrag wl = load_wfrag(pk(ly.n_blocks * 6, 0), P + ly.off_lc_b, di, (di + 15) >> 4);
+      gemm_packed(MT, (di + 15) >> 4, DK, Mat{bX, DS}, wl, [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v; });
       __syncthreads();
       lnin = bQ;
     }
@@ -506,7 +532,7 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
       }
     }
     // ---- last LayerNorm backward: dx -> bK, g * xhat -> bO; dgamma / dbeta as ones-row GEMMs on the matrix cores
-    ln_bwd_rows<false>(bG, lnin, bK, bO, L, LP, DS, dout, P + ly.off_ll_w);
+    ln_bwd_rows<false>(bG, lnin, bK, bO, L, LP, DS, dout, s_ln + (4 * ly.n_blocks) * 64);
     __syncthreads();
     gemm_tiles<0>(1, (dout + 15) >> 4, LP, OnesRow{}, Mat{bG, DS},
                   [=](int r, int c, float v) { if (r == 0 && c < dout) slab[ly.off_ll_b + c] += v; });
@@ -518,15 +544,15 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
       gemm_slab((di + 15) >> 4, NT, LP, MatT{bG, DS}, MatOnes{bX, DS, D},
                 SlabWB{slab + ly.off_lc_w, fold_bias ? slab + ly.off_lc_b : nullptr, di, D, rmw});
       if (!fold_bias) colsum_to_slab(0, bG, DS, L, di, slab + ly.off_lc_b);
-      gemm_packed(MT, NT, (di + 3) & ~3, Mat{bG, DS}, pk(ly.n_blocks * 6, 1), nullptr, 0,
-                  [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });
+      const WFrag wln = load_wfrag(pk(ly.n_blocks * 6, 1), nullptr, 0, NT);
+      gemm_packed(MT, NT, (di + 3) & ~3, Mat{bG, DS}, wln, [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });
       __syncthreads();
       lds_f* t_ = bG; bG = bT; bT = t_;
     }
     tap(a, b, 0, bG, L, D, DS);
 
     for (int i = ly.n_blocks - 1; i >= 0; --i) {
-      const srfrd_block_off o = ly.blk[i];
+      const BlkOff o = blk_off(ly.blk0 + i * ly.blk_stride, D);
       const int tb = 1 + 4 * i;
       const DropSite dsA = drop_site(a.drop_on, seed, site_attn(i), seq, a.drop_thr, a.drop_scale);
       const DropSite ds1 = drop_site(a.drop_on, seed, site_ffn1(i), seq, a.drop_thr, a.drop_scale);
@@ -534,36 +560,38 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
       launder(bX); launder(bQN); launder(bQ); launder(bK); launder(bV); launder(bO); launder(bG); launder(bT);
       launder(S1); launder(S2);
       // ================= FFN half: y = (drop2(a2) + h2) * keep, a2 = relu(drop1(h2 W1^T + b1)) W2^T + b2
+      const WFrag w1t = load_wfrag(pk(i * 6 + 4, 0), P + o.c1_b, D, NT);
+      const WFrag w2n = load_wfrag(pk(i * 6 + 5, 1), nullptr, 0, NT);
+      const WFrag w1n = load_wfrag(pk(i * 6 + 4, 1), nullptr, 0, NT);
       for (int idx = tid; idx < L * D; idx += nthr) {
         const int t = idx / D, c = idx - t * D;
         bG[t * DS + c] *= s_keep[t];
         bX[t * DS + c] = a.c_save_h1[((int64_t)i * B * L + rowbase + t) * D + c];
       }
       __syncthreads();
-      ln_rows(bX, bQN, L, DS, D, P + o.ln2_w, P + o.ln2_b);                        // h2
+      ln_rows(bX, bQN, L, DS, D, s_ln + (4 * i + 2) * 64, s_ln + (4 * i + 3) * 64);      // h2
       for (int idx = tid; idx < LP * D; idx += nthr) {                             // dA2 = drop2'(dy)
         const int t = idx / D, c = idx - t * D;
         bK[t * DS + c] = t < L ? bG[t * DS + c] * drop_mul(ds2, t, c) : 0.f;
       }
       __syncthreads();
-      gemm_packed(MT, NT, DK, Mat{bQN, DS}, pk(i * 6 + 4, 0), P + o.c1_b, D, [&](int r, int c, float v) {
+      gemm_packed(MT, NT, DK, Mat{bQN, DS}, w1t, [&](int r, int c, float v) {
         if (c < D) bQ[r * DS + c] = fmaxf(v * drop_mul(ds1, r, c), 0.f);                        // r = relu(drop1(a1))
       });
       __syncthreads();
       gemm_slab(NT, NT, LP, MatT{bK, DS}, MatOnes{bQ, DS, D},                                   // dW2 += dA2^T r (+ db2)
                 SlabWB{slab + o.c2_w, fold_bias ? slab + o.c2_b : nullptr, D, D, rmw});
       if (!fold_bias) colsum_to_slab(0, bK, DS, L, D, slab + o.c2_b);
-      gemm_packed(MT, NT, DK, Mat{bK, DS}, pk(i * 6 + 5, 1), nullptr, 0, [&](int r, int c, float v) {
+      gemm_packed(MT, NT, DK, Mat{bK, DS}, w2n, [&](int r, int c, float v) {
         if (c < D) bV[r * DS + c] = bQ[r * DS + c] > 0.f ? v * keep_scale : 0.f;               // dA1
       });
       __syncthreads();
       gemm_slab(NT, NT, LP, MatT{bV, DS}, MatOnes{bQN, DS, D},                                  // dW1 += dA1^T h2 (+ db1)
                 SlabWB{slab + o.c1_w, fold_bias ? slab + o.c1_b : nullptr, D, D, rmw});
       if (!fold_bias) colsum_to_slab(1 % nw, bV, DS, L, D, slab + o.c1_b);
-      gemm_packed(MT, NT, DK, Mat{bV, DS}, pk(i * 6 + 4, 1), nullptr, 0,
-                  [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });             // dh2 = dy + dA1 W1
+      gemm_packed(MT, NT, DK, Mat{bV, DS}, w1n, [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });   // dh2 = dy + dA1 W1
       __syncthreads();
-      ln_bwd_rows<false>(bG, bX, bT, bV, L, LP, DS, D, P + o.ln2_w);                           // dh1 -> bT
+      ln_bwd_rows<false>(bG, bX, bT, bV, L, LP, DS, D, s_ln + (4 * i + 2) * 64);               // dh1 -> bT
       __syncthreads();
       gemm_tiles<0>(1, NT, LP, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln2_b + c] += v; });
       gemm_tiles<0>(1, NT, LP, OnesRow{}, Mat{bV, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln2_w + c] += v; });
@@ -576,14 +604,15 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
         bX[t * DS + c] = a.c_save_x[((int64_t)i * B * L + rowbase + t) * D + c];
       }
       __syncthreads();
-      ln_rows(bX, bQN, L, DS, D, P + o.ln1_w, P + o.ln1_b);
+      const WFrag wq = load_wfrag(pk(i * 6 + 0, 0), P + o.in_b, D, NT);
+      const WFrag wk = load_wfrag(pk(i * 6 + 1, 0), P + o.in_b + D, D, NT);
+      const WFrag wv = load_wfrag(pk(i * 6 + 2, 0), P + o.in_b + 2 * D, D, NT);
+      ln_rows(bX, bQN, L, DS, D, s_ln + (4 * i + 0) * 64, s_ln + (4 * i + 1) * 64);
       __syncthreads();
-      gemm_packed(MT, NT, DK, Mat{bQN, DS}, pk(i * 6 + 0, 0), P + o.in_b, D,
-                  [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v * qscale; });
-      gemm_packed(MT, NT, DK, Mat{bX, DS}, pk(i * 6 + 1, 0), P + o.in_b + D, D,
-                  [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v; });
-      gemm_packed(MT, NT, DK, Mat{bX, DS}, pk(i * 6 + 2, 0), P + o.in_b + 2 * D, D,
-                  [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v; });
+      gemm_packed(MT, NT, DK, Mat{bQN, DS}, wq, [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v * qscale; });
+      gemm_packed(MT, NT, DK, Mat{bX, DS}, wk, [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v; });
+      gemm_packed(MT, NT, DK, Mat{bX, DS}, wv, [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v; });
+      const WFrag won = load_wfrag(pk(i * 6 + 3, 1), nullptr, 0, NT);
       __syncthreads();
       gemm_tiles<1>(MT, MT, DK, Mat{bQ, DS}, MatT{bK, DS}, [&](int r, int c, float v) { S1[r * SLD + c] = v; });
       __syncthreads();
@@ -596,8 +625,10 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
                 SlabWB{slab + o.out_w, fold_bias ? slab + o.out_b : nullptr, D, D, rmw});
       if (!fold_bias) colsum_to_slab(2 % nw, bG, DS, L, D, slab + o.out_b);
       __syncthreads();
-      gemm_packed(MT, NT, DK, Mat{bG, DS}, pk(i * 6 + 3, 1), nullptr, 0,
-                  [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });              // do = dh1 Wo
+      gemm_packed(MT, NT, DK, Mat{bG, DS}, won, [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });    // do = dh1 Wo
+      const WFrag wqn = load_wfrag(pk(i * 6 + 0, 1), nullptr, 0, NT);
+      const WFrag wkn = load_wfrag(pk(i * 6 + 1, 1), nullptr, 0, NT);
+      const WFrag wvn = load_wfrag(pk(i * 6 + 2, 1), nullptr, 0, NT);
       __syncthreads();
       gemm_tiles<1>(MT, MT, DK, Mat{bO, DS}, MatT{bV, DS}, [&](int r, int c, float v) { S2[r * SLD + c] = v; });  // dPd = do v^T
       gemm_tiles<3>(MT, NT, LP, MatDropT{S1, SLD, dsA}, Mat{bO, DS},
@@ -622,14 +653,11 @@ __global__ void __launch_bounds__(512) encoder_bwd_kernel(const EncArgs a) {
         colsum_to_slab(1 % nw, dKb, DS, L, D, slab + o.in_b + D);
         colsum_to_slab(2 % nw, bT, DS, L, D, slab + o.in_b + 2 * D);
       }
-      gemm_packed(MT, NT, DK, Mat{bO, DS}, pk(i * 6 + 0, 1), nullptr, 0,
-                  [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });             // dLN1 = dh1 + dq Wq
-      gemm_packed(MT, NT, DK, Mat{dKb, DS}, pk(i * 6 + 1, 1), nullptr, 0,
-                  [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v; });              // dx  = dk Wk
-      gemm_packed(MT, NT, DK, Mat{bT, DS}, pk(i * 6 + 2, 1), nullptr, 0,
-                  [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] += v; });             //     + dv Wv
+      gemm_packed(MT, NT, DK, Mat{bO, DS}, wqn, [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });   // dLN1 = dh1 + dq Wq
+      gemm_packed(MT, NT, DK, Mat{dKb, DS}, wkn, [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v; });   // dx  = dk Wk
+      gemm_packed(MT, NT, DK, Mat{bT, DS}, wvn, [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] += v; });   //     + dv Wv
       __syncthreads();
-      ln_bwd_rows<true>(bG, bX, bQ, S2, L, LP, DS, D, P + o.ln1_w);                            //     + LN1 bwd
+      ln_bwd_rows<true>(bG, bX, bQ, S2, L, LP, DS, D, s_ln + (4 * i + 0) * 64);                //     + LN1 bwd
       __syncthreads();
       gemm_tiles<0>(1, NT, LP, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln1_b + c] += v; });
       gemm_tiles<0>(1, NT, LP, OnesRow{}, Mat{S2, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln1_w + c] += v; });
@@ -734,7 +762,22 @@ static int fill_args(EncArgs& a, const srfrd_layout* lay, const float* item_tabl
   if (L > lay->max_len) return SRFRD_E_ARG;
   if (dropout_p < 0.0 || dropout_p >= 1.0) return SRFRD_E_ARG;
   if (lay->kind == SRFRD_SRFRN && ((pos_ids && !pos_fake) || (neg_ids && !neg_fake))) return SRFRD_E_ARG;
-  a.lay = *lay;
+  Dims& d = a.dm;
+  d.kind = lay->kind; d.d_item = lay->d_item; d.d_fake = lay->d_fake; d.D = lay->D; d.d_out = lay->d_out;
+  d.n_labels = lay->n_labels; d.n_blocks = lay->n_blocks;
+  d.off_pos = (int)lay->off_pos; d.off_side = (int)lay->off_side;
+  d.blk0 = lay->n_blocks > 0 ? (int)lay->blk[0].ln1_w : 0;
+  d.blk_stride = blk_stride_of(lay->D);
+  for (int i = 0; i < lay->n_blocks; ++i) {        // the kernels recompute block offsets arithmetically: check the table agrees
+    const BlkOff o = blk_off(d.blk0 + i * d.blk_stride, lay->D);
+    const srfrd_block_off& t = lay->blk[i];
+    if (t.ln1_w != o.ln1_w || t.ln1_b != o.ln1_b || t.in_w != o.in_w || t.in_b != o.in_b || t.out_w != o.out_w ||
+        t.out_b != o.out_b || t.ln2_w != o.ln2_w || t.ln2_b != o.ln2_b || t.c1_w != o.c1_w || t.c1_b != o.c1_b ||
+        t.c2_w != o.c2_w || t.c2_b != o.c2_b)
+      return SRFRD_E_ARG;
+  }
+  d.off_lc_w = (int)lay->off_lc_w; d.off_lc_b = (int)lay->off_lc_b; d.off_ll_w = (int)lay->off_ll_w; d.off_ll_b = (int)lay->off_ll_b;
+  d.n_dense = (int)lay->n_dense;
   a.table = item_table;
   a.dense = dense;
   a.packed = packed;
@@ -757,7 +800,7 @@ using namespace srfrd;
 extern "C" int srfrd_lds_bytes(const srfrd_layout* lay, int L, int64_t* fwd_bytes, int64_t* bwd_bytes) {
   if (!lay || L <= 0) return SRFRD_E_ARG;
   const Geom g = make_geom(L, lay->D);
-  const int64_t f = fwd_lds_floats(g) * 4, bw = bwd_lds_floats(g) * 4;
+  const int64_t f = fwd_lds_floats(g, lay->n_blocks) * 4, bw = bwd_lds_floats(g, lay->n_blocks) * 4;
   if (fwd_bytes) *fwd_bytes = f <= kLdsLimit ? f : 0;
   if (bwd_bytes) *bwd_bytes = bw <= kLdsLimit ? bw : 0;
   return 0;
@@ -806,7 +849,7 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
   a.dbg = dbg; a.dbg_seq = dbg_seq;
   srfrd_debug_shape(lay, L, &a.dbg_slot, nullptr);
   const Geom g = make_geom(L, lay->D);
-  const int64_t lds = fwd_lds_floats(g) * 4;
+  const int64_t lds = fwd_lds_floats(g, lay->n_blocks) * 4;
   if (lds > kLdsLimit) return SRFRD_E_UNSUPPORTED;
   static int64_t s_attr = 0;
   if (lds > s_attr) {
@@ -841,7 +884,7 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_tabl
   a.dbg = dbg; a.dbg_seq = dbg_seq;
   srfrd_debug_shape(lay, L, &a.dbg_slot, nullptr);
   const Geom g = make_geom(L, lay->D);
-  const int64_t lds = bwd_lds_floats(g) * 4;
+  const int64_t lds = bwd_lds_floats(g, lay->n_blocks) * 4;
   if (lds > kLdsLimit) return SRFRD_E_UNSUPPORTED;
   static int64_t s_attr = 0;
   if (lds > s_attr) {
