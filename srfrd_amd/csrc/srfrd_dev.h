@@ -267,10 +267,9 @@ __device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int
 }
 
 template <class AL, class BL>
-__device__ __forceinline__ void gemm_slab(int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl) {
+__device__ __forceinline__ void gemm_slab(int nw, int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nw = blockDim.x >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int mgroups = nw > n_tiles ? nw / n_tiles : 1;
   const int units = n_tiles * mgroups;
@@ -357,10 +356,9 @@ __device__ __forceinline__ void gemm_group_packed(int mt, int mgroups, int nt, i
 
 // n_tiles <= number of waves (every wave owns at most one strip: the one load_wfrag fetched for it)
 template <class AL, class EPI>
-__device__ __forceinline__ void gemm_packed(int m_tiles, int n_tiles, int k_end, AL a, const WFrag& w, EPI epi) {
+__device__ __forceinline__ void gemm_packed(int nw, int m_tiles, int n_tiles, int k_end, AL a, const WFrag& w, EPI epi) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nw = blockDim.x >> 6;
   const int mgroups = nw > n_tiles ? nw / n_tiles : 1;
   if (wave >= n_tiles * mgroups) return;
   const int nt = wave % n_tiles, g = wave / n_tiles;
@@ -378,10 +376,9 @@ __device__ __forceinline__ void gemm_packed(int m_tiles, int n_tiles, int k_end,
 }
 
 template <int TRI, class AL, class BL, class EPI>
-__device__ __forceinline__ void gemm_tiles(int m_tiles, int n_tiles, int k_end, AL a, BL b, EPI epi) {
+__device__ __forceinline__ void gemm_tiles(int nw, int m_tiles, int n_tiles, int k_end, AL a, BL b, EPI epi) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nw = blockDim.x >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int mgroups = nw > n_tiles ? nw / n_tiles : 1;
   const int units = n_tiles * mgroups;
@@ -421,9 +418,9 @@ __device__ __forceinline__ float quad_max(float v) {
 constexpr int kQC = SRFRD_MAX_D / 4;    // columns per lane of a quad (D <= 64)
 
 // Y[r] = LayerNorm(X[r]) for r < rows   (biased variance, eps inside the sqrt: torch.nn.LayerNorm)
-__device__ __forceinline__ void ln_rows(const lds_f* X, lds_f* Y, int rows, int ld, int D, const lds_f* w,
+__device__ __forceinline__ void ln_rows(int nw, const lds_f* X, lds_f* Y, int rows, int ld, int D, const lds_f* w,
                                         const lds_f* bia) {
-  const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
+  const int q = threadIdx.x & 3, rpp = nw << 4;
   const float invD = 1.0f / (float)D;
   float wl[kQC], bl[kQC];
 #pragma unroll
@@ -463,10 +460,10 @@ __device__ __forceinline__ void ln_rows(const lds_f* X, lds_f* Y, int rows, int 
 //   GXH[r] = g * xhat  -- its column sums are dgamma, those of GY are dbeta; both are taken on the matrix cores by the
 //   caller (ones-row GEMM), so this pass needs no cross-row reduction.
 template <bool ACCUM>
-__device__ __forceinline__ void ln_bwd_rows(const lds_f* GY, const lds_f* X, lds_f* OUT, lds_f* GXH, int rows, int LP, int ld,
-                                            int D, const lds_f* w) {
-  const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
-  for (int i = threadIdx.x; i < (LP - rows) * ld; i += blockDim.x) GXH[rows * ld + i] = 0.f;   // padding rows feed a k-sum
+__device__ __forceinline__ void ln_bwd_rows(int nw, const lds_f* GY, const lds_f* X, lds_f* OUT, lds_f* GXH, int rows, int LP,
+                                            int ld, int D, const lds_f* w) {
+  const int q = threadIdx.x & 3, rpp = nw << 4;
+  for (int i = threadIdx.x; i < (LP - rows) * ld; i += (nw << 6)) GXH[rows * ld + i] = 0.f;   // padding rows feed a k-sum
   const float invD = 1.0f / (float)D;
   float wl[kQC];
 #pragma unroll
@@ -525,8 +522,8 @@ struct OnesRow {        // A operand whose row 0 is all ones (rows 1..15 zero): 
 // once and the loops are fully unrolled (no per-element LDS round trip on the dependency chain).
 constexpr int kSMJ = 32;     // elements per lane: rows up to 128 keys
 template <bool MASKED>
-__device__ __forceinline__ void softmax_rows(lds_f* S, int rows, int sld, int LP, const DropSite& ds) {
-  const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
+__device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld, int LP, const DropSite& ds) {
+  const int q = threadIdx.x & 3, rpp = nw << 4;
   const int nj = LP >> 2;                       // elements per lane (LP is a multiple of 16)
   for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
     lds_f* row = S + r * sld;
@@ -560,8 +557,8 @@ __device__ __forceinline__ void softmax_rows(lds_f* S, int rows, int sld, int LP
 }
 
 // dS = P * (dP - sum_j dP_j P_j), dP = mask * dPd, in place in dPd; rows >= rows (padding) are zeroed up to LP rows
-__device__ __forceinline__ void softmax_bwd_rows(lds_f* dPd, const lds_f* P, int rows, int sld, int LP, const DropSite& ds) {
-  const int q = threadIdx.x & 3, rpp = blockDim.x >> 2;
+__device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f* P, int rows, int sld, int LP, const DropSite& ds) {
+  const int q = threadIdx.x & 3, rpp = nw << 4;
   const int nj = LP >> 2;
   for (int r = threadIdx.x >> 2; r < LP; r += rpp) {
     lds_f* drow = dPd + r * sld;

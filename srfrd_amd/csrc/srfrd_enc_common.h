@@ -1,0 +1,196 @@
+// Shared pieces of the fused encoder translation units (forward / backward): launch arguments, the LayerNorm
+// parameter cache, debug taps, host-side argument marshalling.
+#pragma once
+#include <cstdlib>
+
+#include "srfrd_dev.h"
+
+namespace srfrd {
+
+struct EncArgs {
+  Dims dm;
+  const float* table;
+  const float* dense;
+  const float* packed;      // srfrd_pack_weights output (MFMA-fragment-ordered weights)
+  const int64_t *in_ids, *fk_ids, *pos_ids, *pos_fk, *neg_ids, *neg_fk;
+  int B, L;
+  uint32_t seed;
+  const uint32_t* seed_dev;
+  uint32_t drop_thr;
+  float drop_scale;
+  int drop_on;
+  int64_t seq0;
+  float qscale;
+  // forward outputs
+  float *hidden, *pos_logits, *neg_logits, *save_x, *save_h1, *loss_part;
+  // backward inputs / outputs
+  const float *c_hidden, *c_pl, *c_nl, *c_save_x, *c_save_h1, *d_hidden, *d_pos, *d_neg;
+  int fused_bce;
+  float *grad_table, *grad_slabs;
+  // debug taps
+  float* dbg;
+  int dbg_seq;
+  int64_t dbg_slot;
+};
+
+// Optimisation barrier on a wave-uniform pointer: stops LLVM from hoisting the per-call-site address arithmetic of
+// ~35 inlined GEMMs out of the sequence / block loops (which costs > 256 VGPRs and spills).
+__device__ __forceinline__ void launder(lds_f*& p) {
+  asm volatile("" : "+s"(p));
+}
+__device__ __forceinline__ void launder(const float*& p) {
+  asm volatile("" : "+s"(p));
+}
+__device__ __forceinline__ void launder(float*& p) {
+  asm volatile("" : "+s"(p));
+}
+
+// Diagnostic build only (tools/phase_profile.py compiles a copy with -DSRFRD_STAMPS and a STAMP(n) after every
+// workgroup barrier): thread 0 adds the s_memtime delta of each phase into a per-workgroup table that aliases the
+// debug-tap buffer.  The shipped library contains no stamp.
+#ifdef SRFRD_STAMPS
+#define STAMP_INIT unsigned long long* stamp_acc = (unsigned long long*)a.dbg + (int64_t)blockIdx.x * 128; \
+                   unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(id) do { if (threadIdx.x == 0 && a.dbg) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                       stamp_acc[id] += t_ - stamp_prev; stamp_prev = t_; } } while (0)
+#else
+#define STAMP_INIT
+#define STAMP(id) do {} while (0)
+#endif
+
+// LayerNorm weights / biases -> LDS once per workgroup (read by every row pass of every sequence)
+__device__ __forceinline__ void fill_ln_cache(lds_f* s_ln, const float* P, const Dims& ly) {
+  const int D = ly.D;
+  for (int idx = threadIdx.x; idx < (4 * ly.n_blocks + 2) * 64; idx += blockDim.x) {
+    const int vec = idx >> 6, c = idx & 63;
+    float v = 0.f;
+    if (vec < 4 * ly.n_blocks) {
+      const BlkOff o = blk_off(ly.blk0 + (vec >> 2) * ly.blk_stride, D);
+      const int sel = vec & 3;
+      const int off = sel == 0 ? o.ln1_w : sel == 1 ? o.ln1_b : sel == 2 ? o.ln2_w : o.ln2_b;
+      if (c < D) v = P[off + c];
+    } else if (c < ly.d_out) {
+      v = P[(vec == 4 * ly.n_blocks ? ly.off_ll_w : ly.off_ll_b) + c];
+    }
+    s_ln[idx] = v;
+  }
+}
+
+__device__ __forceinline__ void tap(const EncArgs& a, int b, int slot, const lds_f* buf, int rows, int cols, int ld) {
+#ifdef SRFRD_STAMPS
+  return;
+#endif
+  if (a.dbg == nullptr || b != a.dbg_seq) return;
+  float* dst = a.dbg + (int64_t)slot * a.dbg_slot;
+  for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+    const int r = i / cols, c = i - r * cols;
+    dst[i] = buf[r * ld + c];
+  }
+}
+
+// user label of one sequence from its fake/real ids (reference SRFR_model.py:546-570); wave-uniform result
+__device__ __forceinline__ int user_label_wave(int kind, const int64_t* fk_row, int L, int n_labels) {
+  const int lane = threadIdx.x & 63;
+  int n1 = 0, n2 = 0;
+  if (fk_row != nullptr)
+    for (int t = lane; t < L; t += 64) {
+      const int f = (int)fk_row[t];
+      n1 += (f == 1);
+      n2 += (f == 2);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n1 += __shfl_xor(n1, o, 64);
+    n2 += __shfl_xor(n2, o, 64);
+  }
+  int lab;
+  if (kind == SRFRD_SRFU_B) lab = (n1 < n2) ? 1 : 2;                       // round-half-even(1.5) = 2 on ties
+  else if (kind == SRFRD_SRFU_F) lab = n1;
+  else if (kind == SRFRD_SRFU_R) {
+    const int tot = n1 + n2;                                               // all-pad row: reference is 0/0; guarded to 0
+    lab = tot == 0 ? 0 : (int)floorf(((float)n1 / (float)tot) * 10.0f);
+  } else lab = (n1 > n2) ? 2 : 1;                                          // SRFRN.predict: int() truncation, tie -> 1
+  if (n_labels > 0) lab = min(max(lab, 0), n_labels - 1);
+  return lab;
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static int g_num_cu = 0;
+[[maybe_unused]] static int num_cu() {
+  if (g_num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      g_num_cu = prop.multiProcessorCount;
+    else
+      g_num_cu = 256;
+  }
+  return g_num_cu;
+}
+
+// block size override for tuning runs (multiple of 64, <= 512)
+[[maybe_unused]] static int env_threads(const char* name, int dflt) {
+  const char* e = getenv(name);
+  if (!e) return dflt;
+  const int v = atoi(e);
+  return (v >= 64 && v <= 512 && (v & 63) == 0) ? v : dflt;
+}
+
+[[maybe_unused]] static int fill_args(EncArgs& a, const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
+                     const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids, const int64_t* pos_fake,
+                     const int64_t* neg_ids, const int64_t* neg_fake, int B, int L, double dropout_p, uint32_t seed,
+                     const uint32_t* seed_dev, int64_t seq_index0) {
+  if (!lay || !item_table || !dense || !packed || !input_ids || B <= 0 || L <= 0) return SRFRD_E_ARG;
+  if (lay->D > SRFRD_MAX_D || lay->n_heads != 1 || lay->n_blocks > SRFRD_MAX_BLOCKS) return SRFRD_E_UNSUPPORTED;
+  if (L > lay->max_len) return SRFRD_E_ARG;
+  if (dropout_p < 0.0 || dropout_p >= 1.0) return SRFRD_E_ARG;
+  if (lay->kind == SRFRD_SRFRN && ((pos_ids && !pos_fake) || (neg_ids && !neg_fake))) return SRFRD_E_ARG;
+  Dims& d = a.dm;
+  d.kind = lay->kind; d.d_item = lay->d_item; d.d_fake = lay->d_fake; d.D = lay->D; d.d_out = lay->d_out;
+  d.n_labels = lay->n_labels; d.n_blocks = lay->n_blocks;
+  d.off_pos = (int)lay->off_pos; d.off_side = (int)lay->off_side;
+  d.blk0 = lay->n_blocks > 0 ? (int)lay->blk[0].ln1_w : 0;
+  d.blk_stride = blk_stride_of(lay->D);
+  for (int i = 0; i < lay->n_blocks; ++i) {        // the kernels recompute block offsets arithmetically: check the table agrees
+    const BlkOff o = blk_off(d.blk0 + i * d.blk_stride, lay->D);
+    const srfrd_block_off& t = lay->blk[i];
+    if (t.ln1_w != o.ln1_w || t.ln1_b != o.ln1_b || t.in_w != o.in_w || t.in_b != o.in_b || t.out_w != o.out_w ||
+        t.out_b != o.out_b || t.ln2_w != o.ln2_w || t.ln2_b != o.ln2_b || t.c1_w != o.c1_w || t.c1_b != o.c1_b ||
+        t.c2_w != o.c2_w || t.c2_b != o.c2_b)
+      return SRFRD_E_ARG;
+  }
+  d.off_lc_w = (int)lay->off_lc_w; d.off_lc_b = (int)lay->off_lc_b; d.off_ll_w = (int)lay->off_ll_w; d.off_ll_b = (int)lay->off_ll_b;
+  d.n_dense = (int)lay->n_dense;
+  a.table = item_table;
+  a.dense = dense;
+  a.packed = packed;
+  a.in_ids = input_ids; a.fk_ids = fake_ids; a.pos_ids = pos_ids; a.pos_fk = pos_fake; a.neg_ids = neg_ids; a.neg_fk = neg_fake;
+  a.B = B; a.L = L;
+  a.seed = seed; a.seed_dev = seed_dev;
+  a.drop_on = dropout_p > 0.0;
+  double thr = dropout_p * 4294967296.0;
+  a.drop_thr = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+  a.drop_scale = (float)(1.0 / (1.0 - dropout_p));
+  a.seq0 = seq_index0;
+  a.qscale = (float)sqrt(1.0 / (double)(lay->D / lay->n_heads));
+  return 0;
+}
+
+// launch one instantiation; the > 64 KiB dynamic-LDS opt-in is per function, raised once per instantiation
+template <class K>
+static int launch_enc(K kernel, int grid, int threads, int64_t lds, void* stream, const EncArgs& a) {
+  static int64_t s_attr = 0;      // one static per instantiation of this template (= per kernel instantiation type)
+  static const void* s_fn = nullptr;
+  if (s_fn != (const void*)kernel || lds > s_attr) {
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return SRFRD_E_DEVICE;
+    s_fn = (const void*)kernel;
+    s_attr = lds;
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (size_t)lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace srfrd

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) topk_stage1_kernel(srfrd_layout ly, const
       sF[tid] = s;
     }
     __syncthreads();
-    gemm_tiles<0>(1, kChunk / 16, DKi, Mat{sH, DSi}, MatT{sE, DSi}, [&](int r, int c, float v) {
+    gemm_tiles<0>(nw, 1, kChunk / 16, DKi, Mat{sH, DSi}, MatT{sE, DSi}, [&](int r, int c, float v) {
       if (srfrn) v += sF[r];
       const bool ok = c < n_here && !(exclude_pad && i0 + c == 0);
       sS[r * SLD + c] = ok ? v : -INFINITY;

@@ -7,7 +7,7 @@ using namespace srfrd;
 
 constexpr int LP = 64, D = 50, DS = 54, SLD = 66, NT = 4, MT = 4, DK = 52, L = 50;
 
-template <int V>
+template <int V, int NW>
 __global__ void __launch_bounds__(512) mb(const float* packed, const float* bias, float* slab, unsigned long long* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   lds_f* A = (lds_f*)smem;
@@ -22,30 +22,38 @@ __global__ void __launch_bounds__(512) mb(const float* packed, const float* bias
   DropSite ds = drop_site(1, 123u, 1, blockIdx.x, 0x80000000u, 2.0f);
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
-    if (V == 0) gemm_packed(MT, NT, DK, Mat{A, DS}, w, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; });
-    if (V == 1) { WFrag w2 = load_wfrag(pb, bias, D, NT); gemm_packed(MT, NT, DK, Mat{A, DS}, w2, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; }); }
-    if (V == 2) gemm_tiles<1>(MT, MT, DK, Mat{A, DS}, MatT{Bm, DS}, [&](int r, int c, float v) { S[r * SLD + c] = v; });
-    if (V == 3) gemm_slab(NT, NT, LP, MatT{A, DS}, MatOnes{Bm, DS, D}, SlabWB{slab + blockIdx.x * 4096, slab + blockIdx.x * 4096 + 3000, D, D, 1});
-    if (V == 4) ln_rows(A, Cm, L, DS, D, lnw, lnw + 64);
-    if (V == 5) softmax_rows<true>(S, L, SLD, LP, ds);
+    if (V == 0) gemm_packed(NW, MT, NT, DK, Mat{A, DS}, w, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; });
+    if (V == 1) { WFrag w2 = load_wfrag(pb, bias, D, NT); gemm_packed(NW, MT, NT, DK, Mat{A, DS}, w2, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; }); }
+    if (V == 2) gemm_tiles<1>(NW, MT, MT, DK, Mat{A, DS}, MatT{Bm, DS}, [&](int r, int c, float v) { S[r * SLD + c] = v; });
+    if (V == 3) gemm_slab(NW, NT, NT, LP, MatT{A, DS}, MatOnes{Bm, DS, D}, SlabWB{slab + blockIdx.x * 4096, slab + blockIdx.x * 4096 + 3000, D, D, 1});
+    if (V == 4) ln_rows(NW, A, Cm, L, DS, D, lnw, lnw + 64);
+    if (V == 5) softmax_rows<true>(NW, S, L, SLD, LP, ds);
     if (V == 6) { }
-    if (V == 7) gemm_tiles<2>(MT, NT, LP, Mat{S, SLD}, Mat{Bm, DS}, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; });
-    if (V == 8) gemm_tiles<0>(1, NT, LP, OnesRow{}, Mat{A, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[blockIdx.x * 4096 + c] += v; });
-    if (V == 9) gemm_packed(MT, NT, DK, Mat{A, DS}, w, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = fmaxf(v * drop_mul(ds, r, c), 0.f); });
+    if (V == 7) gemm_tiles<2>(NW, MT, NT, LP, Mat{S, SLD}, Mat{Bm, DS}, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; });
+    if (V == 8) gemm_tiles<0>(NW, 1, NT, LP, OnesRow{}, Mat{A, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[blockIdx.x * 4096 + c] += v; });
+    if (V == 9) gemm_packed(NW, MT, NT, DK, Mat{A, DS}, w, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = fmaxf(v * drop_mul(ds, r, c), 0.f); });
     __syncthreads();
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if (threadIdx.x == 0) out[blockIdx.x] = (t1 - t0);
 }
 
+template <int V, int NW>
+void run1(const char* name, const float* packed, const float* bias, float* slab, unsigned long long* out);
 template <int V>
 void run(const char* name, int threads, const float* packed, const float* bias, float* slab, unsigned long long* out) {
+  if (threads == 256) run1<V, 4>(name, packed, bias, slab, out);
+  else run1<V, 8>(name, packed, bias, slab, out);
+}
+template <int V, int NW>
+void run1(const char* name, const float* packed, const float* bias, float* slab, unsigned long long* out) {
+  const int threads = NW * 64;
   const int iters = 200, grid = 256;
   size_t lds = (3 * LP * DS + LP * SLD + 256) * 4;
-  hipFuncSetAttribute((const void*)mb<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(mb<V>, dim3(grid), dim3(threads), lds, 0, packed, bias, slab, out, iters);
+  hipFuncSetAttribute((const void*)mb<V, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(mb<V, NW>, dim3(grid), dim3(threads), lds, 0, packed, bias, slab, out, iters);
   hipDeviceSynchronize();
-  hipLaunchKernelGGL(mb<V>, dim3(grid), dim3(threads), lds, 0, packed, bias, slab, out, iters);
+  hipLaunchKernelGGL(mb<V, NW>, dim3(grid), dim3(threads), lds, 0, packed, bias, slab, out, iters);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(grid);
   hipMemcpy(h.data(), out, grid * 8, hipMemcpyDeviceToHost);

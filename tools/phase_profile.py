@@ -17,15 +17,32 @@ OUT = os.path.join(ROOT, "srfrd_amd", "lib", "libsrfrd_hip_stamps.so")
 
 
 def build():
-    src = open(os.path.join(CSRC, "srfrd_encoder.hip")).read()
+    labels = {}
+    tmp = "/tmp/srfrd_stamps"
+    os.makedirs(tmp + "/srfrd_amd/csrc", exist_ok=True)
+    os.makedirs(tmp + "/include", exist_ok=True)
+    for which, fname in (("fwd", "srfrd_encoder_fwd.hip"), ("bwd", "srfrd_encoder_bwd.hip")):
+        out = _stamp_file(os.path.join(CSRC, fname), which, labels)
+        open(f"{tmp}/srfrd_amd/csrc/{fname}", "w").write("\n".join(out))
+    for f in ("srfrd_dev.h", "srfrd_rng.h", "srfrd_enc_common.h", "srfrd_optim.hip", "srfrd_rank.hip"):
+        open(f"{tmp}/srfrd_amd/csrc/{f}", "w").write(open(os.path.join(CSRC, f)).read())
+    open(f"{tmp}/include/srfrd_hip.h", "w").write(open(os.path.join(ROOT, "include", "srfrd_hip.h")).read())
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
+           "-DSRFRD_STAMPS", "-o", OUT] + [f"{tmp}/srfrd_amd/csrc/{f}" for f in
+                                           ("srfrd_encoder_fwd.hip", "srfrd_encoder_bwd.hip", "srfrd_optim.hip", "srfrd_rank.hip")]
+    subprocess.run(cmd, check=True)
+    import json
+    json.dump({f"{k[0]}:{k[1]}": v for k, v in labels.items()}, open(OUT + ".labels.json", "w"), indent=0)
+
+
+def _stamp_file(path, which, labels):
+    src = open(path).read()
     lines = src.split("\n")
-    out, labels, n, kernel = [], {}, 0, None
+    out, n, kernel = [], 0, None
     for ln, line in enumerate(lines):
         out.append(line)
-        if "void __launch_bounds__(512) encoder_fwd_kernel" in line:
-            kernel, n = "fwd", 0
-        elif "void __launch_bounds__(512) encoder_bwd_kernel" in line:
-            kernel, n = "bwd", 0
+        if "encoder_%s_kernel(const EncArgs a) {" % which in line:
+            kernel, n = which, 0
         elif line == "}":
             kernel = None
         if kernel and line.strip() == "__syncthreads();" and n < 120:
@@ -36,18 +53,7 @@ def build():
                 out.append(f"    STAMP({n});")
                 labels[(kernel, n)] = f"L{ln + 1}: {prev[:90]}"
                 n += 1
-    tmp = "/tmp/srfrd_stamps"
-    os.makedirs(tmp + "/srfrd_amd/csrc", exist_ok=True)
-    os.makedirs(tmp + "/include", exist_ok=True)
-    for f in ("srfrd_dev.h", "srfrd_rng.h", "srfrd_optim.hip", "srfrd_rank.hip"):
-        open(f"{tmp}/srfrd_amd/csrc/{f}", "w").write(open(os.path.join(CSRC, f)).read())
-    open(f"{tmp}/include/srfrd_hip.h", "w").write(open(os.path.join(ROOT, "include", "srfrd_hip.h")).read())
-    open(f"{tmp}/srfrd_amd/csrc/srfrd_encoder.hip", "w").write("\n".join(out))
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
-           "-DSRFRD_STAMPS", "-o", OUT] + [f"{tmp}/srfrd_amd/csrc/{f}" for f in ("srfrd_encoder.hip", "srfrd_optim.hip", "srfrd_rank.hip")]
-    subprocess.run(cmd, check=True)
-    import json
-    json.dump({f"{k[0]}:{k[1]}": v for k, v in labels.items()}, open(OUT + ".labels.json", "w"), indent=0)
+    return out
 
 
 def _after_init(out, kernel):
@@ -55,7 +61,7 @@ def _after_init(out, kernel):
     for l in reversed(out):
         if l.strip() == "STAMP_INIT":
             return True
-        if "__launch_bounds__(512) encoder_" in l:
+        if "_kernel(const EncArgs a) {" in l:
             return False
     return False
 
