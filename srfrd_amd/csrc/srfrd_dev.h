@@ -75,7 +75,7 @@ __host__ __device__ __forceinline__ int64_t fwd_lds_floats(const Geom& g, int n_
   return (int64_t)imax(g.LP * g.DS, g.LP * g.SLD) + 4ll * g.LP * g.DS + kSlack + 4ll * g.LP + 64 + ln_cache_floats(n_blocks);
 }
 __host__ __device__ __forceinline__ int64_t bwd_lds_floats(const Geom& g, int n_blocks) {
-  return 8ll * g.LP * g.DS + 2ll * imax(g.LP * g.SLD, g.LP * g.DS) + kSlack + 10ll * g.LP + 64 + ln_cache_floats(n_blocks);
+  return 8ll * g.LP * g.DS + 2ll * imax(g.LP * g.SLD, g.LP * g.DS) + kSlack + 10ll * g.LP + 64 + 2ll * ln_cache_floats(n_blocks);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -242,19 +242,47 @@ __device__ __forceinline__ void gemm_group(int mt, int mgroups, int n0, int k_en
   }
 }
 
-// slab (dW) variant of gemm_group: preloads C, always full k range
-template <int G, class AL, class BL>
-__device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int k_end, const AL& a, const BL& b,
-                                                const SlabWB& sl, int li, int lq) {
-  float* ptrs[G][4];
-  float old[G][4];
+constexpr int kMW = 4;     // row tiles a wave accumulates at once
+
+// Old slab values of the (<= kMW) row tiles a wave owns in a dW GEMM, requested ahead of time (slab_preload) so the
+// L2 / Infinity-Cache latency of the read-modify-write hides under whatever the workgroup does in between.
+struct SlabPre {
+  float v[kMW][4];
+};
+
+// tiles of this wave in a (m_tiles x n_tiles) GEMM with m_tiles <= kMW * mgroups: unit, strip, first tile, count
+struct WaveTiles {
+  int active, nt, g, mgroups, n;
+};
+__device__ __forceinline__ WaveTiles wave_tiles(int nw, int m_tiles, int n_tiles) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  WaveTiles t;
+  t.mgroups = nw > n_tiles ? nw / n_tiles : 1;
+  t.active = wave < n_tiles * t.mgroups;
+  t.nt = wave % n_tiles;
+  t.g = wave / n_tiles;
+  t.n = t.active && t.g < m_tiles ? (m_tiles - t.g + t.mgroups - 1) / t.mgroups : 0;
+  return t;
+}
+
+__device__ __forceinline__ SlabPre slab_preload(int nw, int m_tiles, int n_tiles, const SlabWB& sl) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+  const WaveTiles t = wave_tiles(nw, m_tiles, n_tiles);
+  SlabPre p;
 #pragma unroll
-  for (int j = 0; j < G; ++j)
+  for (int j = 0; j < kMW; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      ptrs[j][e] = sl.ptr(((mt + j * mgroups) << 4) + (lq << 2) + e, n0 + li);
-      old[j][e] = (sl.rmw && ptrs[j][e] != nullptr) ? *ptrs[j][e] : 0.f;
+      float* ptr = (j < t.n) ? sl.ptr(((t.g + j * t.mgroups) << 4) + (lq << 2) + e, (t.nt << 4) + li) : nullptr;
+      p.v[j][e] = (sl.rmw && ptr != nullptr) ? *ptr : 0.f;
     }
+  return p;
+}
+
+// dW group: C-in from `pre` (tiles J0 .. J0+G-1 of this wave), full k range, plain store of C-in + acc
+template <int G, int J0, class AL, class BL>
+__device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int k_end, const AL& a, const BL& b,
+                                                const SlabWB& sl, const SlabPre& pre, int li, int lq) {
   f32x4 acc[G];
 #pragma unroll
   for (int j = 0; j < G; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -262,31 +290,29 @@ __device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int
 #pragma unroll
   for (int j = 0; j < G; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (ptrs[j][e] != nullptr) *ptrs[j][e] = old[j][e] + acc[j][e];
+    for (int e = 0; e < 4; ++e) {
+      float* ptr = sl.ptr(((mt + j * mgroups) << 4) + (lq << 2) + e, n0 + li);
+      if (ptr != nullptr) *ptr = pre.v[J0 + j][e] + acc[j][e];
+    }
 }
 
+// m_tiles <= kMW * mgroups and n_tiles <= number of waves (true for every weight-gradient GEMM: <= 4 x 4 tiles)
+template <class AL, class BL>
+__device__ __forceinline__ void gemm_slab(int nw, int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl, const SlabPre& pre) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+  const WaveTiles t = wave_tiles(nw, m_tiles, n_tiles);
+  const int n0 = t.nt << 4;
+  if (t.n >= 4) gemm_group_slab<4, 0>(t.g, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
+  else {
+    if (t.n >= 2) gemm_group_slab<2, 0>(t.g, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
+    if (t.n == 3) gemm_group_slab<1, 2>(t.g + 2 * t.mgroups, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
+    if (t.n == 1) gemm_group_slab<1, 0>(t.g, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
+  }
+}
 template <class AL, class BL>
 __device__ __forceinline__ void gemm_slab(int nw, int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 15, lq = lane >> 4;
-  const int mgroups = nw > n_tiles ? nw / n_tiles : 1;
-  const int units = n_tiles * mgroups;
-  for (int u = wave; u < units; u += nw) {
-    const int nt = u % n_tiles, g = u / n_tiles;
-    const int n0 = nt << 4;
-    int mt = g;
-    while (mt + 3 * mgroups < m_tiles) {
-      gemm_group_slab<4>(mt, mgroups, n0, k_end, a, b, sl, li, lq);
-      mt += 4 * mgroups;
-    }
-    if (mt + mgroups < m_tiles) {
-      gemm_group_slab<2>(mt, mgroups, n0, k_end, a, b, sl, li, lq);
-      mt += 2 * mgroups;
-    }
-    if (mt < m_tiles) gemm_group_slab<1>(mt, mgroups, n0, k_end, a, b, sl, li, lq);
-  }
+  const SlabPre pre = slab_preload(nw, m_tiles, n_tiles, sl);
+  gemm_slab(nw, m_tiles, n_tiles, k_end, a, b, sl, pre);
 }
 
 // Weight fragments of the strip this wave owns in a packed GEMM, requested ahead of use (one phase early where the
@@ -521,8 +547,10 @@ struct OnesRow {        // A operand whose row 0 is all ones (rows 1..15 zero): 
 // A quad owns a row; each lane keeps its (up to kSMJ) elements in registers, so the row is read once and written
 // once and the loops are fully unrolled (no per-element LDS round trip on the dependency chain).
 constexpr int kSMJ = 32;     // elements per lane: rows up to 128 keys
+// MASKED = true : S <- mask * P (forward).   MASKED = false: S <- P and, if S_masked != nullptr, S_masked <- mask * P
 template <bool MASKED>
-__device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld, int LP, const DropSite& ds) {
+__device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld, int LP, const DropSite& ds,
+                                             lds_f* S_masked = nullptr) {
   const int q = threadIdx.x & 3, rpp = nw << 4;
   const int nj = LP >> 2;                       // elements per lane (LP is a multiple of 16)
   for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
@@ -551,6 +579,7 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
         float p = x[i] / s;                      // exact zero above the diagonal (x = 0)
         if (MASKED) p *= drop_mul(ds, r, j);
         row[j] = p;
+        if (!MASKED && S_masked != nullptr) S_masked[r * sld + j] = p * drop_mul(ds, r, j);
       }
     }
   }

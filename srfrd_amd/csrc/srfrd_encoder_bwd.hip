@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
   lds_f* s_dnl = tail + 8 * LP;
   lds_f* s_misc = tail + 10 * LP;        // 64
   lds_f* s_ln = s_misc + 64;             // LayerNorm parameter cache
+  lds_f* s_lng = s_ln + ln_cache_floats(ly.n_blocks);   // LayerNorm parameter-gradient accumulators (same indexing)
   {
     const int total = (int)bwd_lds_floats(g, ly.n_blocks);
     for (int i = tid; i < total; i += nthr) lds0[i] = 0.f;
@@ -155,44 +156,49 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
       __syncthreads();
       lnin = bQ;
     }
-    // ---- logits backward.  Pass 1 (one quad per position): dh -> bG, hidden rows staged in bT.
+    // ---- logits backward.  Pass 1: dh -> bG and the hidden rows -> bT.  Threads walk (position, channel) linearly, so a
+    // wave reads each gathered item row as one contiguous 4*d_item-byte segment (the rows sit anywhere in the table).
     {
-      const int q = tid & 3;
       const bool srfrn = kind == SRFRD_SRFRN;
-      for (int t = tid >> 2; t < L; t += nthr >> 2) {
+      int t = tid / dout, c = tid - t * dout;
+      const int dt = nthr / dout, dc = nthr - dt * dout;
+      for (; t < L; ) {
+        const float h = a.c_hidden[(rowbase + t) * dout + c];
+        float dh = a.d_hidden ? a.d_hidden[(rowbase + t) * dout + c] : 0.f;
         const float dp = s_dpl[t], dn = s_dnl[t];
-        const int pid = s_pid[t], nid = s_nid[t], pf = s_pfk[t], nf = s_nfk[t];
-#pragma unroll
-        for (int j = 0; j < kQC; ++j) {
-          const int c = q + 4 * j;
-          if (c < D) {
-            float dh = 0.f;
-            if (c < dout) {
-              bT[t * DS + c] = a.c_hidden[(rowbase + t) * dout + c];
-              if (a.d_hidden) dh = a.d_hidden[(rowbase + t) * dout + c];
-              if (c < di) {
-                if (a.pos_ids) dh += dp * table[(int64_t)pid * di + c];
-                if (a.neg_ids) dh += dn * table[(int64_t)nid * di + c];
-              } else if (srfrn) {
-                if (a.pos_ids) dh += dp * P[ly.off_side + pf * dfk + (c - di)];
-                if (a.neg_ids) dh += dn * P[ly.off_side + nf * dfk + (c - di)];
-              }
-            }
-            bG[t * DS + c] = dh;
-          }
+        if (c < di) {
+          if (a.pos_ids) dh += dp * table[(int64_t)s_pid[t] * di + c];
+          if (a.neg_ids) dh += dn * table[(int64_t)s_nid[t] * di + c];
+        } else if (srfrn) {
+          if (a.pos_ids) dh += dp * P[ly.off_side + s_pfk[t] * dfk + (c - di)];
+          if (a.neg_ids) dh += dn * P[ly.off_side + s_nfk[t] * dfk + (c - di)];
         }
+        bT[t * DS + c] = h;
+        bG[t * DS + c] = dh;
+        t += dt; c += dc;
+        if (c >= dout) { c -= dout; ++t; }
       }
+      if (dout < D)                                    // SRFR: channels d_out..D-1 of the LN input gradient are zero
+        for (int idx = tid; idx < L * (D - dout); idx += nthr) {
+          const int tt = idx / (D - dout), cc = dout + idx - tt * (D - dout);
+          bG[tt * DS + cc] = 0.f;
+        }
     }
     __syncthreads();
-    // Pass 2 (one wave per position, lane = channel): item-table scatter as whole 4*d_item-byte row segments, the
-    // access shape float atomics run at full rate for; row 0 (padding_idx) receives none.
-    for (int t = wave; t < L; t += nw) {
-      if (lane < di) {
-        const float h = bT[t * DS + lane];
+    // Pass 2: item-table scatter (float atomics, no return), again linear in (position, channel): every wave-instruction
+    // adds to at most two contiguous row segments - the shape the memory-side atomic units run at full rate for.
+    // Row 0 (padding_idx) receives none.
+    {
+      int t = tid / di, c = tid - t * di;
+      const int dt = nthr / di, dc = nthr - dt * di;
+      for (; t < L; ) {
+        const float h = bT[t * DS + c];
         const float dp = s_dpl[t], dn = s_dnl[t];
         const int pid = s_pid[t], nid = s_nid[t];
-        if (a.pos_ids && pid != 0 && dp != 0.f) atomicAdd(&a.grad_table[(int64_t)pid * di + lane], dp * h);
-        if (a.neg_ids && nid != 0 && dn != 0.f) atomicAdd(&a.grad_table[(int64_t)nid * di + lane], dn * h);
+        if (a.pos_ids && pid != 0 && dp != 0.f) atomicAdd(&a.grad_table[(int64_t)pid * di + c], dp * h);
+        if (a.neg_ids && nid != 0 && dn != 0.f) atomicAdd(&a.grad_table[(int64_t)nid * di + c], dn * h);
+        t += dt; c += dc;
+        if (c >= di) { c -= di; ++t; }
       }
     }
     if (kind == SRFRD_SRFRN && wave == (1 % nw) && lane < dfk && (a.pos_ids || a.neg_ids)) {
@@ -209,9 +215,9 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
     ln_bwd_rows<false>(nw, bG, lnin, bK, bO, L, LP, DS, dout, s_ln + (4 * ly.n_blocks) * 64);
     __syncthreads();
     gemm_tiles<0>(nw, 1, (dout + 15) >> 4, LP, OnesRow{}, Mat{bG, DS},
-                  [=](int r, int c, float v) { if (r == 0 && c < dout) slab[ly.off_ll_b + c] += v; });
+                  [=](int r, int c, float v) { if (r == 0 && c < dout) s_lng[(4 * ly.n_blocks + 1) * 64 + c] += v; });
     gemm_tiles<0>(nw, 1, (dout + 15) >> 4, LP, OnesRow{}, Mat{bO, DS},
-                  [=](int r, int c, float v) { if (r == 0 && c < dout) slab[ly.off_ll_w + c] += v; });
+                  [=](int r, int c, float v) { if (r == 0 && c < dout) s_lng[(4 * ly.n_blocks + 0) * 64 + c] += v; });
     __syncthreads();
     { lds_f* t_ = bG; bG = bK; bK = t_; }
     if (kind == SRFRD_SRFR) {             // hc = hf Wlc^T + blc
@@ -237,6 +243,11 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
       const WFrag w1t = load_wfrag(pk(i * 6 + 4, 0), P + o.c1_b, D, NT);
       const WFrag w2n = load_wfrag(pk(i * 6 + 5, 1), nullptr, 0, NT);
       const WFrag w1n = load_wfrag(pk(i * 6 + 4, 1), nullptr, 0, NT);
+      // old slab values of this block's FFN weight gradients, requested three phases before they are needed
+      const SlabWB sl_w2{slab + o.c2_w, fold_bias ? slab + o.c2_b : nullptr, D, D, rmw};
+      const SlabWB sl_w1{slab + o.c1_w, fold_bias ? slab + o.c1_b : nullptr, D, D, rmw};
+      const SlabPre pre_w2 = slab_preload(nw, NT, NT, sl_w2);
+      const SlabPre pre_w1 = slab_preload(nw, NT, NT, sl_w1);
       for (int idx = tid; idx < L * D; idx += nthr) {
         const int t = idx / D, c = idx - t * D;
         bG[t * DS + c] *= s_keep[t];
@@ -253,22 +264,20 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
         if (c < D) bQ[r * DS + c] = fmaxf(v * drop_mul(ds1, r, c), 0.f);                        // r = relu(drop1(a1))
       });
       __syncthreads();
-      gemm_slab(nw, NT, NT, LP, MatT{bK, DS}, MatOnes{bQ, DS, D},                                   // dW2 += dA2^T r (+ db2)
-                SlabWB{slab + o.c2_w, fold_bias ? slab + o.c2_b : nullptr, D, D, rmw});
+      gemm_slab(nw, NT, NT, LP, MatT{bK, DS}, MatOnes{bQ, DS, D}, sl_w2, pre_w2);                   // dW2 += dA2^T r (+ db2)
       if (!fold_bias) colsum_to_slab(0, bK, DS, L, D, slab + o.c2_b);
       gemm_packed(nw, MT, NT, DK, Mat{bK, DS}, w2n, [&](int r, int c, float v) {
         if (c < D) bV[r * DS + c] = bQ[r * DS + c] > 0.f ? v * keep_scale : 0.f;               // dA1
       });
       __syncthreads();
-      gemm_slab(nw, NT, NT, LP, MatT{bV, DS}, MatOnes{bQN, DS, D},                                  // dW1 += dA1^T h2 (+ db1)
-                SlabWB{slab + o.c1_w, fold_bias ? slab + o.c1_b : nullptr, D, D, rmw});
+      gemm_slab(nw, NT, NT, LP, MatT{bV, DS}, MatOnes{bQN, DS, D}, sl_w1, pre_w1);                  // dW1 += dA1^T h2 (+ db1)
       if (!fold_bias) colsum_to_slab(1 % nw, bV, DS, L, D, slab + o.c1_b);
       gemm_packed(nw, MT, NT, DK, Mat{bV, DS}, w1n, [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });   // dh2 = dy + dA1 W1
       __syncthreads();
       ln_bwd_rows<false>(nw, bG, bX, bT, bV, L, LP, DS, D, s_ln + (4 * i + 2) * 64);               // dh1 -> bT
       __syncthreads();
-      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln2_b + c] += v; });
-      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{bV, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln2_w + c] += v; });
+      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 3) * 64 + c] += v; });
+      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{bV, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 2) * 64 + c] += v; });
       __syncthreads();
       { lds_f* t_ = bG; bG = bT; bT = t_; }
       tap(a, b, tb + 0, bG, L, D, DS);
@@ -287,26 +296,34 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
       gemm_packed(nw, MT, NT, DK, Mat{bX, DS}, wk, [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v; });
       gemm_packed(nw, MT, NT, DK, Mat{bX, DS}, wv, [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v; });
       const WFrag won = load_wfrag(pk(i * 6 + 3, 1), nullptr, 0, NT);
+      const SlabWB sl_wo{slab + o.out_w, fold_bias ? slab + o.out_b : nullptr, D, D, rmw};
+      const SlabPre pre_wo = slab_preload(nw, NT, NT, sl_wo);
       __syncthreads();
       gemm_tiles<1>(nw, MT, MT, DK, Mat{bQ, DS}, MatT{bK, DS}, [&](int r, int c, float v) { S1[r * SLD + c] = v; });
       __syncthreads();
-      softmax_rows<false>(nw, S1, L, SLD, LP, dsA);                  // P (dropout NOT folded in: applied on load)
+      softmax_rows<false>(nw, S1, L, SLD, LP, dsA, S2);              // S1 <- P (for dS), S2 <- dropout(P) (for o and dv)
       __syncthreads();
-      gemm_tiles<2>(nw, MT, NT, LP, MatDrop{S1, SLD, dsA}, Mat{bV, DS},
+      gemm_tiles<2>(nw, MT, NT, LP, Mat{S2, SLD}, Mat{bV, DS},
                     [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });            // o = drop(P) v
       __syncthreads();
-      gemm_slab(nw, NT, NT, LP, MatT{bG, DS}, MatOnes{bO, DS, D},                                   // dWo += dh1^T o (+ dbo)
-                SlabWB{slab + o.out_w, fold_bias ? slab + o.out_b : nullptr, D, D, rmw});
+      gemm_slab(nw, NT, NT, LP, MatT{bG, DS}, MatOnes{bO, DS, D}, sl_wo, pre_wo);                   // dWo += dh1^T o (+ dbo)
       if (!fold_bias) colsum_to_slab(2 % nw, bG, DS, L, D, slab + o.out_b);
       __syncthreads();
       gemm_packed(nw, MT, NT, DK, Mat{bG, DS}, won, [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });    // do = dh1 Wo
       const WFrag wqn = load_wfrag(pk(i * 6 + 0, 1), nullptr, 0, NT);
       const WFrag wkn = load_wfrag(pk(i * 6 + 1, 1), nullptr, 0, NT);
       const WFrag wvn = load_wfrag(pk(i * 6 + 2, 1), nullptr, 0, NT);
+      const SlabWB sl_wq{slab + o.in_w, fold_bias ? slab + o.in_b : nullptr, D, D, rmw};
+      const SlabWB sl_wk{slab + o.in_w + D * D, fold_bias ? slab + o.in_b + D : nullptr, D, D, rmw};
+      const SlabWB sl_wv{slab + o.in_w + 2 * D * D, fold_bias ? slab + o.in_b + 2 * D : nullptr, D, D, rmw};
+      const SlabPre pre_wq = slab_preload(nw, NT, NT, sl_wq);
+      const SlabPre pre_wk = slab_preload(nw, NT, NT, sl_wk);
+      const SlabPre pre_wv = slab_preload(nw, NT, NT, sl_wv);
+      __syncthreads();
+      gemm_tiles<3>(nw, MT, NT, LP, MatT{S2, SLD}, Mat{bO, DS},
+                    [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });            // dv = drop(P)^T do
       __syncthreads();
       gemm_tiles<1>(nw, MT, MT, DK, Mat{bO, DS}, MatT{bV, DS}, [&](int r, int c, float v) { S2[r * SLD + c] = v; });  // dPd = do v^T
-      gemm_tiles<3>(nw, MT, NT, LP, MatDropT{S1, SLD, dsA}, Mat{bO, DS},
-                    [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });            // dv = drop(P)^T do
       __syncthreads();
       softmax_bwd_rows(nw, S2, S1, L, SLD, LP, dsA);                 // dS = P * (dP - sum_j dP_j P_j), dP = mask * dPd
       __syncthreads();
@@ -316,12 +333,9 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
       gemm_tiles<3>(nw, MT, NT, LP, MatT{S2, SLD}, Mat{bQ, DS},
                     [&](int r, int c, float v) { if (c < D) dKb[r * DS + c] = v; });           // dk = dS^T q
       __syncthreads();
-      gemm_slab(nw, NT, NT, LP, MatT{bO, DS}, MatOnes{bQN, DS, D},                                  // dWq (+ dbq)
-                SlabWB{slab + o.in_w, fold_bias ? slab + o.in_b : nullptr, D, D, rmw});
-      gemm_slab(nw, NT, NT, LP, MatT{dKb, DS}, MatOnes{bX, DS, D},                                  // dWk (+ dbk)
-                SlabWB{slab + o.in_w + D * D, fold_bias ? slab + o.in_b + D : nullptr, D, D, rmw});
-      gemm_slab(nw, NT, NT, LP, MatT{bT, DS}, MatOnes{bX, DS, D},                                   // dWv (+ dbv)
-                SlabWB{slab + o.in_w + 2 * D * D, fold_bias ? slab + o.in_b + 2 * D : nullptr, D, D, rmw});
+      gemm_slab(nw, NT, NT, LP, MatT{bO, DS}, MatOnes{bQN, DS, D}, sl_wq, pre_wq);                  // dWq (+ dbq)
+      gemm_slab(nw, NT, NT, LP, MatT{dKb, DS}, MatOnes{bX, DS, D}, sl_wk, pre_wk);                  // dWk (+ dbk)
+      gemm_slab(nw, NT, NT, LP, MatT{bT, DS}, MatOnes{bX, DS, D}, sl_wv, pre_wv);                   // dWv (+ dbv)
       if (!fold_bias) {
         colsum_to_slab(0, bO, DS, L, D, slab + o.in_b);
         colsum_to_slab(1 % nw, dKb, DS, L, D, slab + o.in_b + D);
@@ -333,8 +347,8 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
       __syncthreads();
       ln_bwd_rows<true>(nw, bG, bX, bQ, S2, L, LP, DS, D, s_ln + (4 * i + 0) * 64);                //     + LN1 bwd
       __syncthreads();
-      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln1_b + c] += v; });
-      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{S2, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[o.ln1_w + c] += v; });
+      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 1) * 64 + c] += v; });
+      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{S2, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 0) * 64 + c] += v; });
       __syncthreads();
       lds_f* t_ = bG; bG = bQ; bQ = t_;
       tap(a, b, tb + 1, bG, L, D, DS);
@@ -343,15 +357,17 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
     // ---- embedding backward: item rows (atomics), position table, side channel
     {
       const DropSite dsE = drop_site(a.drop_on && is_sas, seed, SITE_EMB, seq, a.drop_thr, a.drop_scale);
-      for (int t = wave; t < L; t += nw) {
-        if (lane < D) {
-          float gv = bG[t * DS + lane] * s_keep[t];
-          if (is_sas) gv *= drop_mul(dsE, t, lane);
+      {
+        int t = tid / di, c = tid - t * di;
+        const int dt = nthr / di, dc = nthr - dt * di;
+        for (; t < L; ) {
+          float gv = bG[t * DS + c] * s_keep[t];
+          if (is_sas) gv *= drop_mul(dsE, t, c);
           const int id = s_in[t];
-          if (lane < di) {
-            if (id != 0) atomicAdd(&a.grad_table[(int64_t)id * di + lane], is_sas ? gv * sqrtD : gv);
-            slab[ly.off_pos + t * di + lane] += gv;
-          }
+          if (id != 0) atomicAdd(&a.grad_table[(int64_t)id * di + c], is_sas ? gv * sqrtD : gv);
+          slab[ly.off_pos + t * di + c] += gv;          // (t, c) is owned by the same thread for every sequence
+          t += dt; c += dc;
+          if (c >= di) { c -= di; ++t; }
         }
       }
       if (has_fake && wave == (1 % nw) && lane < dfk) {
@@ -370,6 +386,17 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
       }
     }
     __syncthreads();
+  }
+  // LayerNorm parameter gradients: LDS accumulators -> slab (same vector indexing as the parameter cache)
+  for (int idx = tid; idx < (4 * ly.n_blocks + 2) * 64; idx += nthr) {
+    const int vec = idx >> 6, c = idx & 63;
+    if (vec < 4 * ly.n_blocks) {
+      const BlkOff o = blk_off(ly.blk0 + (vec >> 2) * ly.blk_stride, D);
+      const int sel = vec & 3;
+      if (c < D) slab[(sel == 0 ? o.ln1_w : sel == 1 ? o.ln1_b : sel == 2 ? o.ln2_w : o.ln2_b) + c] = s_lng[idx];
+    } else if (c < dout) {
+      slab[(vec == 4 * ly.n_blocks ? ly.off_ll_w : ly.off_ll_b) + c] = s_lng[idx];
+    }
   }
 }
 
