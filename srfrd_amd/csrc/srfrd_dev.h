@@ -333,10 +333,11 @@ __device__ __forceinline__ WFrag load_wfrag(PackedB b, const float* bias, int nb
   return f;
 }
 
-// packed-weight GEMM: C = A * Bpacked (+ bias[col]); k_end <= 64.  k runs over whole 16-deep chunks: the packed
-// weights are zero beyond K, and A over-reads stay inside LDS on finite data, so the tail needs no predication.
+// packed-weight GEMM: C = A * Bpacked (+ bias[col]); k_end <= 64, a multiple of 4.  Exactly k_end / 4 MFMA k-steps are
+// issued (13 at D = 50, not 16): the step count per 16-deep chunk is wave-uniform and, in the specialised kernels, a
+// compile-time constant, so the chunk bodies stay branch-free there.
 template <int G, class AL, class EPI>
-__device__ __forceinline__ void gemm_group_packed(int mt, int mgroups, int nt, int nchunks, const AL& a, const WFrag& w,
+__device__ __forceinline__ void gemm_group_packed(int mt, int mgroups, int nt, int ksteps, const AL& a, const WFrag& w,
                                                   const EPI& epi, int lane) {
   const int li = lane & 15, lq = lane >> 4;
   const int n0 = nt << 4;
@@ -347,22 +348,26 @@ __device__ __forceinline__ void gemm_group_packed(int mt, int mgroups, int nt, i
   float av[4][G];
 #pragma unroll
   for (int s = 0; s < 4; ++s)
+    if (s < ksteps)
 #pragma unroll
-    for (int j = 0; j < G; ++j) av[s][j] = a(mrow + j * mstride, 4 * s + lq);
+      for (int j = 0; j < G; ++j) av[s][j] = a(mrow + j * mstride, 4 * s + lq);
 #pragma unroll
   for (int kc = 0; kc < kPackKC; ++kc) {
-    if (kc < nchunks) {
-      const int kn = min(kc + 1, nchunks - 1) << 4;
+    const int nst = ksteps - 4 * kc;           // k-steps of this chunk (>= 4: full)
+    if (nst > 0) {
+      const int nnext = nst - 4;               // k-steps of the next chunk
       float an[4][G];
 #pragma unroll
       for (int s = 0; s < 4; ++s)
+        if (s < nnext)
 #pragma unroll
-        for (int j = 0; j < G; ++j) an[s][j] = a(mrow + j * mstride, kn + 4 * s + lq);
+          for (int j = 0; j < G; ++j) an[s][j] = a(mrow + j * mstride, ((kc + 1) << 4) + 4 * s + lq);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
+        if (s < nst)
 #pragma unroll
-        for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][j], w.q[kc][s], acc[j], 0, 0, 0);
+          for (int j = 0; j < G; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][j], w.q[kc][s], acc[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -388,7 +393,7 @@ __device__ __forceinline__ void gemm_packed(int nw, int m_tiles, int n_tiles, in
   const int mgroups = nw > n_tiles ? nw / n_tiles : 1;
   if (wave >= n_tiles * mgroups) return;
   const int nt = wave % n_tiles, g = wave / n_tiles;
-  const int nchunks = (k_end + 15) >> 4;
+  const int nchunks = k_end >> 2;      // MFMA k-steps (k_end is a multiple of 4)
   int mt = g;
   while (mt + 3 * mgroups < m_tiles) {
     gemm_group_packed<4>(mt, mgroups, nt, nchunks, a, w, epi, lane);

@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
   const int D = D_ > 0 ? D_ : ly.D;
   const int LP = LP_ > 0 ? LP_ : ((L + 15) & ~15);
   const int DK = (D + 3) & ~3, DS = DK + 2, SLD = LP + 2, NT = (D + 15) >> 4, MT = LP >> 4;
+  const int LK = (L + 3) & ~3;           // token k-range of the gradient GEMMs: rows >= L of every gradient matrix are zero
   Geom g;
   g.L = L; g.LP = LP; g.D = D; g.DK = DK; g.DS = DS; g.SLD = SLD; g.NT = NT; g.MT = MT;
   const int szA = LP * DS, szS = imax(LP * SLD, szA);
@@ -214,14 +215,14 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
     // ---- last LayerNorm backward: dx -> bK, g * xhat -> bO; dgamma / dbeta as ones-row GEMMs on the matrix cores
     ln_bwd_rows<false>(nw, bG, lnin, bK, bO, L, LP, DS, dout, s_ln + (4 * ly.n_blocks) * 64);
     __syncthreads();
-    gemm_tiles<0>(nw, 1, (dout + 15) >> 4, LP, OnesRow{}, Mat{bG, DS},
+    gemm_tiles<0>(nw, 1, (dout + 15) >> 4, LK, OnesRow{}, Mat{bG, DS},
                   [=](int r, int c, float v) { if (r == 0 && c < dout) s_lng[(4 * ly.n_blocks + 1) * 64 + c] += v; });
-    gemm_tiles<0>(nw, 1, (dout + 15) >> 4, LP, OnesRow{}, Mat{bO, DS},
+    gemm_tiles<0>(nw, 1, (dout + 15) >> 4, LK, OnesRow{}, Mat{bO, DS},
                   [=](int r, int c, float v) { if (r == 0 && c < dout) s_lng[(4 * ly.n_blocks + 0) * 64 + c] += v; });
     __syncthreads();
     { lds_f* t_ = bG; bG = bK; bK = t_; }
     if (kind == SRFRD_SRFR) {             // hc = hf Wlc^T + blc
-      gemm_slab(nw, (di + 15) >> 4, NT, LP, MatT{bG, DS}, MatOnes{bX, DS, D},
+      gemm_slab(nw, (di + 15) >> 4, NT, LK, MatT{bG, DS}, MatOnes{bX, DS, D},
                 SlabWB{slab + ly.off_lc_w, fold_bias ? slab + ly.off_lc_b : nullptr, di, D, rmw});
       if (!fold_bias) colsum_to_slab(0, bG, DS, L, di, slab + ly.off_lc_b);
       const WFrag wln = load_wfrag(pk(ly.n_blocks * 6, 1), nullptr, 0, NT);
@@ -264,20 +265,20 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
         if (c < D) bQ[r * DS + c] = fmaxf(v * drop_mul(ds1, r, c), 0.f);                        // r = relu(drop1(a1))
       });
       __syncthreads();
-      gemm_slab(nw, NT, NT, LP, MatT{bK, DS}, MatOnes{bQ, DS, D}, sl_w2, pre_w2);                   // dW2 += dA2^T r (+ db2)
+      gemm_slab(nw, NT, NT, LK, MatT{bK, DS}, MatOnes{bQ, DS, D}, sl_w2, pre_w2);                   // dW2 += dA2^T r (+ db2)
       if (!fold_bias) colsum_to_slab(0, bK, DS, L, D, slab + o.c2_b);
       gemm_packed(nw, MT, NT, DK, Mat{bK, DS}, w2n, [&](int r, int c, float v) {
         if (c < D) bV[r * DS + c] = bQ[r * DS + c] > 0.f ? v * keep_scale : 0.f;               // dA1
       });
       __syncthreads();
-      gemm_slab(nw, NT, NT, LP, MatT{bV, DS}, MatOnes{bQN, DS, D}, sl_w1, pre_w1);                  // dW1 += dA1^T h2 (+ db1)
+      gemm_slab(nw, NT, NT, LK, MatT{bV, DS}, MatOnes{bQN, DS, D}, sl_w1, pre_w1);                  // dW1 += dA1^T h2 (+ db1)
       if (!fold_bias) colsum_to_slab(1 % nw, bV, DS, L, D, slab + o.c1_b);
       gemm_packed(nw, MT, NT, DK, Mat{bV, DS}, w1n, [&](int r, int c, float v) { if (c < D) bG[r * DS + c] += v; });   // dh2 = dy + dA1 W1
       __syncthreads();
       ln_bwd_rows<false>(nw, bG, bX, bT, bV, L, LP, DS, D, s_ln + (4 * i + 2) * 64);               // dh1 -> bT
       __syncthreads();
-      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 3) * 64 + c] += v; });
-      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{bV, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 2) * 64 + c] += v; });
+      gemm_tiles<0>(nw, 1, NT, LK, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 3) * 64 + c] += v; });
+      gemm_tiles<0>(nw, 1, NT, LK, OnesRow{}, Mat{bV, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 2) * 64 + c] += v; });
       __syncthreads();
       { lds_f* t_ = bG; bG = bT; bT = t_; }
       tap(a, b, tb + 0, bG, L, D, DS);
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
       gemm_tiles<2>(nw, MT, NT, LP, Mat{S2, SLD}, Mat{bV, DS},
                     [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });            // o = drop(P) v
       __syncthreads();
-      gemm_slab(nw, NT, NT, LP, MatT{bG, DS}, MatOnes{bO, DS, D}, sl_wo, pre_wo);                   // dWo += dh1^T o (+ dbo)
+      gemm_slab(nw, NT, NT, LK, MatT{bG, DS}, MatOnes{bO, DS, D}, sl_wo, pre_wo);                   // dWo += dh1^T o (+ dbo)
       if (!fold_bias) colsum_to_slab(2 % nw, bG, DS, L, D, slab + o.out_b);
       __syncthreads();
       gemm_packed(nw, MT, NT, DK, Mat{bG, DS}, won, [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v; });    // do = dh1 Wo
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
       const SlabPre pre_wk = slab_preload(nw, NT, NT, sl_wk);
       const SlabPre pre_wv = slab_preload(nw, NT, NT, sl_wv);
       __syncthreads();
-      gemm_tiles<3>(nw, MT, NT, LP, MatT{S2, SLD}, Mat{bO, DS},
+      gemm_tiles<3>(nw, MT, NT, LK, MatT{S2, SLD}, Mat{bO, DS},
                     [&](int r, int c, float v) { if (c < D) bT[r * DS + c] = v; });            // dv = drop(P)^T do
       __syncthreads();
       gemm_tiles<1>(nw, MT, MT, DK, Mat{bO, DS}, MatT{bV, DS}, [&](int r, int c, float v) { S2[r * SLD + c] = v; });  // dPd = do v^T
@@ -330,12 +331,12 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
       lds_f* dKb = S1;                                           // P is dead: dk overlays it as [LP][DS]
       gemm_tiles<2>(nw, MT, NT, LP, Mat{S2, SLD}, Mat{bK, DS},
                     [&](int r, int c, float v) { if (c < D) bO[r * DS + c] = v * qscale; });   // dq (pre-scale)
-      gemm_tiles<3>(nw, MT, NT, LP, MatT{S2, SLD}, Mat{bQ, DS},
+      gemm_tiles<3>(nw, MT, NT, LK, MatT{S2, SLD}, Mat{bQ, DS},
                     [&](int r, int c, float v) { if (c < D) dKb[r * DS + c] = v; });           // dk = dS^T q
       __syncthreads();
-      gemm_slab(nw, NT, NT, LP, MatT{bO, DS}, MatOnes{bQN, DS, D}, sl_wq, pre_wq);                  // dWq (+ dbq)
-      gemm_slab(nw, NT, NT, LP, MatT{dKb, DS}, MatOnes{bX, DS, D}, sl_wk, pre_wk);                  // dWk (+ dbk)
-      gemm_slab(nw, NT, NT, LP, MatT{bT, DS}, MatOnes{bX, DS, D}, sl_wv, pre_wv);                   // dWv (+ dbv)
+      gemm_slab(nw, NT, NT, LK, MatT{bO, DS}, MatOnes{bQN, DS, D}, sl_wq, pre_wq);                  // dWq (+ dbq)
+      gemm_slab(nw, NT, NT, LK, MatT{dKb, DS}, MatOnes{bX, DS, D}, sl_wk, pre_wk);                  // dWk (+ dbk)
+      gemm_slab(nw, NT, NT, LK, MatT{bT, DS}, MatOnes{bX, DS, D}, sl_wv, pre_wv);                   // dWv (+ dbv)
       if (!fold_bias) {
         colsum_to_slab(0, bO, DS, L, D, slab + o.in_b);
         colsum_to_slab(1 % nw, dKb, DS, L, D, slab + o.in_b + D);
@@ -347,8 +348,8 @@ __global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_bwd_kernel(c
       __syncthreads();
       ln_bwd_rows<true>(nw, bG, bX, bQ, S2, L, LP, DS, D, s_ln + (4 * i + 0) * 64);                //     + LN1 bwd
       __syncthreads();
-      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 1) * 64 + c] += v; });
-      gemm_tiles<0>(nw, 1, NT, LP, OnesRow{}, Mat{S2, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 0) * 64 + c] += v; });
+      gemm_tiles<0>(nw, 1, NT, LK, OnesRow{}, Mat{bG, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 1) * 64 + c] += v; });
+      gemm_tiles<0>(nw, 1, NT, LK, OnesRow{}, Mat{S2, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) s_lng[(4 * i + 0) * 64 + c] += v; });
       __syncthreads();
       lds_f* t_ = bG; bG = bQ; bQ = t_;
       tap(a, b, tb + 1, bG, L, D, DS);

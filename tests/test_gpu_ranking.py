@@ -1,0 +1,152 @@
+"""-m gpu: full-catalog top-k, batched evaluation and the C2-size (BASELINE.json configs[1]) property tests."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import srfrd_oracle as O
+from tests.helpers import golden_cfg, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind", ["SASRec", "SRFR", "SRFRN", "SRFU_F"])
+def test_topk_matches_oracle_bit_exact(kind):
+    """fused top-10 over the whole catalog == stable descending sort of the oracle's logits (indices bit-exact)."""
+    from tests.gpu_util import build_model
+    g, sd, batch = load_golden(kind)
+    cfg = golden_cfg(kind)
+    model = build_model(cfg, sd).eval()
+    idx, val = model.topk(None, batch[0].cuda(), batch[1].cuda(), k=10)
+    all_items = torch.arange(1, cfg.item_number + 1)
+    ref = O.predict(cfg, sd, batch[0], batch[1], all_items)             # (B, I)
+    order = np.argsort(-ref.numpy(), axis=1, kind="stable")[:, :10]
+    assert (idx.cpu().numpy() == order + 1).all()
+    assert float((val.cpu() - torch.gather(ref, 1, torch.from_numpy(order))).abs().max()) < 1e-4
+    # including the padding item 0 and a sub-range of the catalog (row-sharded table use case)
+    idx0, _ = model.topk(None, batch[0].cuda(), batch[1].cuda(), k=5, exclude_pad=False, item_range=(0, 64))
+    ref0 = O.predict(cfg, sd, batch[0], batch[1], torch.arange(0, 64))
+    assert (idx0.cpu().numpy() == np.argsort(-ref0.numpy(), axis=1, kind="stable")[:, :5]).all()
+
+
+def test_topk_tie_break_prefers_lower_item_id():
+    import srfrd_amd
+    m = srfrd_amd.SASRec(700, 20, 50, 0.0, 1, 1, "cuda").cuda().eval()
+    with torch.no_grad():
+        m.item_emb.weight[1:] = m.item_emb.weight[1:2]                 # every item scores identically
+    seq = torch.randint(1, 700, (3, 20)).cuda()
+    idx, val = m.topk(None, seq, None, k=7)
+    assert (idx.cpu() == torch.arange(1, 8)).all() and float((val - val[:, :1]).abs().max()) == 0.0
+
+
+def test_batched_evaluation_matches_oracle_metric():
+    """HR@10 / NDCG@10 over 101 candidates per user (reference utils.py:576-598) for a golden model."""
+    import srfrd_amd
+    from tests.gpu_util import build_model
+    g, sd, batch = load_golden("SRFU_B")
+    cfg = golden_cfg("SRFU_B")
+    model = build_model(cfg, sd).eval()
+    cands = torch.from_numpy(g["cands"])
+    ndcg, hr = srfrd_amd.evaluate_batches(model, [(None, batch[0][:4].cuda(), batch[1][:4].cuda(), cands[:4].cuda()),
+                                                  (None, batch[0][4:].cuda(), batch[1][4:].cuda(), cands[4:].cuda())])
+    ranks = O.rank_of_first(torch.from_numpy(g["pred_logits"]))
+    nd, h = O.hr_ndcg_at_10(ranks)
+    assert abs(ndcg - nd) < 1e-12 and abs(hr - h) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C2 size: 50 000 items, seq_len 50, batch 512 - too large for the CPU oracle in seconds, so size-independent
+# properties of the path are checked instead
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c2():
+    import srfrd_amd
+    torch.manual_seed(0)
+    m = srfrd_amd.SASRec(50_000, 50, 50, 0.5, 2, 1, "cuda")
+    for _, p in m.named_parameters():
+        if p.dim() >= 2:
+            torch.nn.init.xavier_normal_(p.data)
+    m = m.cuda()
+    batch = srfrd_amd.synthetic_batch(50_000, 50, 512, seed=1, device="cuda")
+    return m, batch
+
+
+def test_c2_forward_deterministic_causal_and_batch_invariant(c2):
+    m, (u, seq, rsq, pos, prs, neg, nrs) = c2
+    m.eval()
+    with torch.no_grad():
+        h1, p1, n1 = m(u, seq, rsq, pos, prs, neg, nrs)
+        h2, p2, n2 = m(u, seq, rsq, pos, prs, neg, nrs)
+        assert torch.equal(h1, h2) and torch.equal(p1, p2) and torch.equal(n1, n2)          # bitwise repeatable
+        # a sequence's result does not depend on its neighbours or its slot in the batch
+        perm = torch.randperm(512, device="cuda")
+        h3, p3, _ = m(u, seq[perm][:100], rsq, pos[perm][:100], prs, neg[perm][:100], nrs)
+        assert torch.equal(h3, h1[perm][:100]) and torch.equal(p3, p1[perm][:100])
+        # causality: changing the last item leaves every earlier position untouched
+        seq2 = seq.clone()
+        seq2[:, -1] = (seq2[:, -1] % 49_999) + 1
+        h4, _, _ = m(u, seq2, rsq, pos, prs, neg, nrs)
+        assert torch.equal(h4[:, :-1], h1[:, :-1]) and not torch.equal(h4[:, -1], h1[:, -1])
+        # padded positions are fed zeros: logits there equal <LN-of-constant, E[0]>, identical across rows with pads
+        assert bool(torch.isfinite(h1).all())
+
+
+def test_c2_gradients_are_linear_in_the_upstream_gradient(c2):
+    m, (u, seq, rsq, pos, prs, neg, nrs) = c2
+    m.eval()                                              # dropout off: exact linearity
+    ids = m._prep(seq, None, pos, None, neg, None)
+    out = m._launch_fwd(*ids, 0.0, 0, save=True)
+    g1 = torch.randn_like(out["pos_logits"])
+    g2 = torch.randn_like(out["neg_logits"])
+    a = m._launch_bwd(*ids, 0.0, 0, out, None, g1, g2)
+    b = m._launch_bwd(*ids, 0.0, 0, out, None, 2 * g1, 2 * g2)
+    dense = slice(m.n_table_pad, m.n_table_pad + m.layout.n_dense)
+    assert torch.equal(b[dense], 2 * a[dense])                                   # dense part: bitwise (fixed-order sums)
+    assert float((b[:m.layout.n_table] - 2 * a[:m.layout.n_table]).abs().max()) < 1e-4   # table: float atomics
+    rows = a[:m.layout.n_table].view(-1, 50)
+    assert float(rows[0].abs().max()) == 0.0                                      # padding_idx row never written
+    touched = torch.unique(torch.cat([seq.flatten(), pos.flatten(), neg.flatten()]))
+    mask = torch.ones(rows.shape[0], dtype=torch.bool, device="cuda")
+    mask[touched] = False
+    assert float(rows[mask].abs().max()) == 0.0                                   # untouched rows get exactly zero
+
+
+def test_c2_fused_step_equals_autograd_step_and_learns(c2):
+    import copy
+    import srfrd_amd
+    m, (u, seq, rsq, pos, prs, neg, nrs) = c2
+    m1, m2 = copy.deepcopy(m), copy.deepcopy(m)
+    m1.dropout_rate = m2.dropout_rate = 0.0
+    m1.train(); m2.train()
+    tr = srfrd_amd.FusedTrainer(m1, 512, 50, use_graph=True)
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    crit = torch.nn.BCEWithLogitsLoss()
+    losses = []
+    for step in range(3):
+        l1 = tr.step(u, seq, rsq, pos, prs, neg, nrs)
+        h, pl, nl = m2(u, seq, rsq, pos, prs, neg, nrs)
+        idx = torch.where(pos != 0)
+        l2 = crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
+        opt.zero_grad()
+        l2.backward()
+        opt.step()
+        assert abs(float(l1) - float(l2.detach())) < 1e-5
+        losses.append(float(l1))
+    assert losses[2] < losses[0]                                                  # it trains
+    # Weights: Adam divides by sqrt(v), so an element whose gradient is at rounding-noise level moves by +-O(lr) per step
+    # with a noise-determined sign (see tests/helpers.drop_kbias); the two paths differ in summation order (1/count
+    # applied before vs after the backward, float-atomic order).  Hence: bounded by 3 steps * lr everywhere, and equal
+    # to ~1e-6 on average.
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        d = (sd1[k] - sd2[k]).abs()
+        assert float(d.max()) < 3.1e-3 and float(d.mean()) < 1e-4, k
+
+
+def test_c2_untrained_hit_rate_is_chance(c2):
+    import srfrd_amd
+    m, (u, seq, rsq, pos, prs, neg, nrs) = c2
+    cand = srfrd_amd.eval_candidates(50_000, seq, pos[:, -1], 100, seed=3)
+    ndcg, hr = srfrd_amd.evaluate_batches(m, [(u, seq, rsq, cand)])
+    assert 0.04 < hr < 0.18                       # 10 / 101 for a random ranker (512 users)
+    idx, val = m.topk(u, seq, rsq, k=10)
+    assert idx.shape == (512, 10) and bool((val[:, :-1] >= val[:, 1:]).all()) and bool((idx >= 1).all())

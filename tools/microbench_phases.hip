@@ -8,7 +8,7 @@ using namespace srfrd;
 constexpr int LP = 64, D = 50, DS = 54, SLD = 66, NT = 4, MT = 4, DK = 52, L = 50;
 
 template <int V, int NW>
-__global__ void __launch_bounds__(512) mb(const float* packed, const float* bias, float* slab, unsigned long long* out, int iters) {
+__global__ void __launch_bounds__(NW * 64) mb(const float* packed, const float* bias, float* slab, unsigned long long* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   lds_f* A = (lds_f*)smem;
   lds_f* Bm = A + LP * DS;
@@ -43,7 +43,8 @@ void run1(const char* name, const float* packed, const float* bias, float* slab,
 template <int V>
 void run(const char* name, int threads, const float* packed, const float* bias, float* slab, unsigned long long* out) {
   if (threads == 256) run1<V, 4>(name, packed, bias, slab, out);
-  else run1<V, 8>(name, packed, bias, slab, out);
+  else if (threads == 512) run1<V, 8>(name, packed, bias, slab, out);
+  else run1<V, 16>(name, packed, bias, slab, out);
 }
 template <int V, int NW>
 void run1(const char* name, const float* packed, const float* bias, float* slab, unsigned long long* out) {
@@ -51,9 +52,9 @@ void run1(const char* name, const float* packed, const float* bias, float* slab,
   const int iters = 200, grid = 256;
   size_t lds = (3 * LP * DS + LP * SLD + 256) * 4;
   hipFuncSetAttribute((const void*)mb<V, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(mb<V, NW>, dim3(grid), dim3(threads), lds, 0, packed, bias, slab, out, iters);
+  hipLaunchKernelGGL((mb<V, NW>), dim3(grid), dim3(threads), lds, 0, packed, bias, slab, out, iters);
   hipDeviceSynchronize();
-  hipLaunchKernelGGL(mb<V, NW>, dim3(grid), dim3(threads), lds, 0, packed, bias, slab, out, iters);
+  hipLaunchKernelGGL((mb<V, NW>), dim3(grid), dim3(threads), lds, 0, packed, bias, slab, out, iters);
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(grid);
   hipMemcpy(h.data(), out, grid * 8, hipMemcpyDeviceToHost);
@@ -72,7 +73,7 @@ int main() {
   hipMemset(packed, 0, 4096 * 4 * 4);
   hipMemset(bias, 0, 256);
   hipMemset(slab, 0, 256 * 4096 * 4);
-  for (int threads : {256, 512}) {
+  for (int threads : {256, 512, 1024}) {
     run<6>("empty phase (barrier only)", threads, packed, bias, slab, out);
     run<0>("gemm_packed, fragments preloaded", threads, packed, bias, slab, out);
     run<1>("gemm_packed + load_wfrag each phase", threads, packed, bias, slab, out);
