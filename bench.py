@@ -74,6 +74,21 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("SRFRD_CPU_THREADS", "16"))))
 
 
+def pmc_traffic(kernel_c_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    separate passes, read side doubled as MI355X_MICROARCH.md prescribes for gfx950); None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        ks = json.load(open(path))["kernels"]
+    except Exception:
+        return None
+    stem = kernel_c_name.replace("srfrd_", "") + "_kernel"          # srfrd_encoder_bwd -> encoder_bwd_kernel
+    for name, d in ks.items():
+        if name.startswith(stem) and "hbm_bytes_per_launch" in d and "<0, 0, 0>" not in name:
+            return d["hbm_bytes_per_launch"]["total"]
+    return None
+
+
 def cpu_baseline(cfg, budget_s=12.0):
     """The oracle's restated trainer.py:27-41 step (torch CPU ops, dropout on) timed on this host's cores."""
     from oracle import srfrd_oracle as O
@@ -190,7 +205,7 @@ def main():
                        "global_batch": world * B, "seq_len": L, "n_items": cfg["n_items"],
                        "parallelism": f"dp{world}", "graph": not args.no_graph, "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
                          "avg_kernel_ms": kt[dom], "algorithmic_flops_per_launch": dom_flops,
                          "kernel_ms": kt,
                          "step_hbm": {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,
