@@ -77,8 +77,14 @@ int srfrd_layout_init(srfrd_layout* lay, int kind, int n_items, int max_len, int
                       int n_labels, int n_blocks, int n_heads);
 
 /* [host] capability query: dynamic LDS bytes the fused forward / backward kernels need for sequence length L
- * (0 if L does not fit the 160 KiB LDS of a gfx950 CU). */
+ * (0 if L does not fit the 160 KiB LDS of a gfx950 CU: such shapes take the global-scratch build, see
+ * srfrd_scratch_floats). */
 int srfrd_lds_bytes(const srfrd_layout* lay, int L, int64_t* fwd_bytes, int64_t* bwd_bytes);
+
+/* [host] floats of global scratch the forward / backward need for (B, L): 0 when the sequence's working set fits LDS;
+ * otherwise the kernels run their long-sequence build, which keeps that working set in `scratch` (one slice per
+ * workgroup) - every shape runs on the GPU, the LDS-resident shapes run faster. */
+int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64_t* fwd_floats, int64_t* bwd_floats);
 
 /* [host] number of persistent workgroups the backward launches for batch B (= rows of `grad_slabs`). */
 int srfrd_bwd_grid(int B);
@@ -111,6 +117,7 @@ int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packe
  *  save_x (n_blocks+1, B, L, D): block inputs and the last block's output; save_h1 (n_blocks, B, L, D):
  *    post-attention residual; both NULL for inference
  *  loss_part (B,3) or NULL: per sequence {sum softplus(-pos), sum softplus(neg), count} over pos_ids != 0
+ *  scratch / scratch_floats: srfrd_scratch_floats() floats of workspace (NULL / 0 when that is 0)
  *  dbg / dbg_seq: debug taps of one sequence (tests only; NULL otherwise)
  */
 int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
@@ -120,6 +127,7 @@ int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const fl
                       int B, int L, double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
                       float* hidden, float* pos_logits, float* neg_logits,
                       float* save_x, float* save_h1, float* loss_part,
+                      float* scratch, int64_t scratch_floats,
                       float* dbg, int dbg_seq, void* stream);
 
 /*
@@ -141,6 +149,7 @@ int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const fl
                       const float* save_x, const float* save_h1,
                       const float* d_hidden, const float* d_pos, const float* d_neg, int fused_bce,
                       float* grad_table, float* grad_slabs,
+                      float* scratch, int64_t scratch_floats,
                       float* dbg, int dbg_seq, void* stream);
 
 /* Sums the per-workgroup slabs into grad_dense (n_dense) in a fixed order (bitwise reproducible) and, if

@@ -38,14 +38,15 @@ _LP = C.POINTER(Layout)
 SIGNATURES = {
     "srfrd_layout_init": (_i, [_LP, _i, _i, _i, _i, _i, _i, _i, _i]),
     "srfrd_lds_bytes": (_i, [_LP, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "srfrd_scratch_floats": (_i, [_LP, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "srfrd_bwd_grid": (_i, [_i]),
     "srfrd_debug_shape": (_i, [_LP, _i, C.POINTER(_i64), C.POINTER(C.c_int32)]),
     "srfrd_packed_floats": (_i64, [_LP]),
     "srfrd_pack_weights": (_i, [_LP, _P, _P, _P]),
     "srfrd_encoder_fwd": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
-                               _P, _P, _P, _P, _P, _P, _P, _i, _P]),
+                               _P, _P, _P, _P, _P, _P, _P, _i64, _P, _i, _P]),
     "srfrd_encoder_bwd": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
-                               _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, _i, _P]),
+                               _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, _i64, _P, _i, _P]),
     "srfrd_reduce_dense": (_i, [_P, _i, _i64, _P, _P, _i, _P, _P]),
     "srfrd_step_begin": (_i, [_P, _d, _d, _d, _P]),
     "srfrd_adam_step": (_i, [_P, _P, _P, _P, _i64, _i64, _i64, _i64, _d, _d, _d, _P, _P, _P]),
@@ -101,4 +102,10 @@ def make_layout(kind: str, n_items: int, max_len: int, d_item: int, d_fake: int 
 def lds_bytes(lay: Layout, L: int):
     f, b = _i64(0), _i64(0)
     check(lib().srfrd_lds_bytes(C.byref(lay), L, C.byref(f), C.byref(b)), "srfrd_lds_bytes")
+    return f.value, b.value
+
+
+def scratch_floats(lay: Layout, B: int, L: int):
+    f, b = _i64(0), _i64(0)
+    check(lib().srfrd_scratch_floats(C.byref(lay), B, L, C.byref(f), C.byref(b)), "srfrd_scratch_floats")
     return f.value, b.value

@@ -15,13 +15,28 @@
 #include "../../include/srfrd_hip.h"
 #include "srfrd_rng.h"
 
-namespace srfrd {
+// Two builds of the same sources: the default keeps a sequence's working set in LDS; with SRFRD_BUF_GLOBAL the same
+// kernels address a per-workgroup scratch in global memory instead (sequences too long for the 160 KiB LDS: slower,
+// but every shape runs on the GPU).  The variants live in different namespaces so both link into one library.
+#ifdef SRFRD_BUF_GLOBAL
+#define SRFRD_NS srfrd_long
+#else
+#define SRFRD_NS srfrd
+#endif
+
+namespace SRFRD_NS {
+using namespace srfrd;   // srfrd_rng.h
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef SRFRD_BUF_GLOBAL
+typedef float lds_f;
+typedef int lds_i;
+#else
 // LDS-resident matrices are addressed through explicit address_space(3) pointers: a generic `float*` that the
 // compiler cannot trace back to __shared__ becomes flat_load/flat_store with 64-bit address arithmetic.
 typedef __attribute__((address_space(3))) float lds_f;
 typedef __attribute__((address_space(3))) int lds_i;
+#endif
 
 constexpr float kLnEps = 1e-8f;   // reference SRFR_model.py:77,80,86
 constexpr int kLdsLimit = 160 * 1024;
@@ -558,6 +573,28 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
                                              lds_f* S_masked = nullptr) {
   const int q = threadIdx.x & 3, rpp = nw << 4;
   const int nj = LP >> 2;                       // elements per lane (LP is a multiple of 16)
+  if (nj > kSMJ) {                              // rows longer than 4 * kSMJ keys: streaming three-pass form
+    for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
+      lds_f* row = S + r * sld;
+      float m = -INFINITY;
+      for (int j = q; j <= r; j += 4) m = fmaxf(m, row[j]);
+      m = quad_max(m);
+      float s = 0.f;
+      for (int j = q; j <= r; j += 4) {
+        const float e = __expf(row[j] - m);
+        row[j] = e;
+        s += e;
+      }
+      s = quad_sum(s);
+      for (int j = q; j < LP; j += 4) {
+        float p = j <= r ? row[j] / s : 0.f;
+        if (MASKED) p *= drop_mul(ds, r, j);
+        row[j] = p;
+        if (!MASKED && S_masked != nullptr) S_masked[r * sld + j] = p * drop_mul(ds, r, j);
+      }
+    }
+    return;
+  }
   for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
     lds_f* row = S + r * sld;
     float x[kSMJ];
@@ -594,6 +631,25 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
 __device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f* P, int rows, int sld, int LP, const DropSite& ds) {
   const int q = threadIdx.x & 3, rpp = nw << 4;
   const int nj = LP >> 2;
+  if (nj > kSMJ) {                              // long rows: streaming form
+    for (int r = threadIdx.x >> 2; r < LP; r += rpp) {
+      lds_f* drow = dPd + r * sld;
+      const lds_f* prow = P + r * sld;
+      if (r < rows) {
+        float acc = 0.f;
+        for (int j = q; j <= r; j += 4) {
+          const float d = drow[j] * drop_mul(ds, r, j);
+          drow[j] = d;
+          acc += d * prow[j];
+        }
+        acc = quad_sum(acc);
+        for (int j = q; j < LP; j += 4) drow[j] = j <= r ? prow[j] * (drow[j] - acc) : 0.f;
+      } else {
+        for (int j = q; j < LP; j += 4) drow[j] = 0.f;
+      }
+    }
+    return;
+  }
   for (int r = threadIdx.x >> 2; r < LP; r += rpp) {
     lds_f* drow = dPd + r * sld;
     const lds_f* prow = P + r * sld;
@@ -620,4 +676,4 @@ __device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f
 __device__ __forceinline__ float softplus_f(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
 __device__ __forceinline__ float sigmoid_f(float z) { return 1.0f / (1.0f + expf(-z)); }
 
-}  // namespace srfrd
+}  // namespace SRFRD_NS

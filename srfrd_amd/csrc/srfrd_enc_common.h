@@ -5,7 +5,7 @@
 
 #include "srfrd_dev.h"
 
-namespace srfrd {
+namespace SRFRD_NS {
 
 struct EncArgs {
   Dims dm;
@@ -27,6 +27,9 @@ struct EncArgs {
   const float *c_hidden, *c_pl, *c_nl, *c_save_x, *c_save_h1, *d_hidden, *d_pos, *d_neg;
   int fused_bce;
   float *grad_table, *grad_slabs;
+  // SRFRD_BUF_GLOBAL build only: per-workgroup working-set scratch (floats) in global memory
+  float* scratch;
+  int64_t scratch_stride;
   // debug taps
   float* dbg;
   int dbg_seq;
@@ -38,12 +41,14 @@ struct EncArgs {
 __device__ __forceinline__ void launder(lds_f*& p) {
   asm volatile("" : "+s"(p));
 }
+#ifndef SRFRD_BUF_GLOBAL
 __device__ __forceinline__ void launder(const float*& p) {
   asm volatile("" : "+s"(p));
 }
 __device__ __forceinline__ void launder(float*& p) {
   asm volatile("" : "+s"(p));
 }
+#endif
 
 // Diagnostic build only (tools/phase_profile.py compiles a copy with -DSRFRD_STAMPS and a STAMP(n) after every
 // workgroup barrier): thread 0 adds the s_memtime delta of each phase into a per-workgroup table that aliases the
@@ -193,4 +198,4 @@ static int launch_enc(K kernel, int grid, int threads, int64_t lds, void* stream
   return (int)hipGetLastError();
 }
 
-}  // namespace srfrd
+}  // namespace SRFRD_NS

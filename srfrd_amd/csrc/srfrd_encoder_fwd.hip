@@ -9,238 +9,9 @@
 // tensors; eps = 1e-8.
 #include "srfrd_enc_common.h"
 
+#include "srfrd_encoder_fwd_kernel.inc"
+
 namespace srfrd {
-
-// ================================================================================================
-// forward
-// ================================================================================================
-// D_, LP_, NW_ > 0: geometry and wave count fixed at compile time (strides become immediates, tile loops
-// resolve statically); 0: read at run time (the generic instantiation covers every other shape).
-template <int D_, int LP_, int NW_>
-__global__ void __launch_bounds__(NW_ > 0 ? NW_ * 64 : 512) encoder_fwd_kernel(const EncArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Dims& ly = a.dm;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nw = NW_ > 0 ? NW_ : (int)(blockDim.x >> 6), nthr = nw << 6;
-  const int L = a.L;
-  const int D = D_ > 0 ? D_ : ly.D;
-  const int LP = LP_ > 0 ? LP_ : ((L + 15) & ~15);
-  const int DK = (D + 3) & ~3, DS = DK + 2, SLD = LP + 2, NT = (D + 15) >> 4, MT = LP >> 4;
-  Geom g;
-  g.L = L; g.LP = LP; g.D = D; g.DK = DK; g.DS = DS; g.SLD = SLD; g.NT = NT; g.MT = MT;
-  const int szA = LP * DS, szX = imax(szA, LP * SLD);
-  lds_f* const lds0 = (lds_f*)smem;
-  lds_f* bXS = lds0;
-  lds_f* bQN = bXS + szX;
-  lds_f* bQ = bQN + szA;
-  lds_f* bK = bQ + szA;
-  lds_f* bV = bK + szA;
-  lds_f* tail = bV + szA + kSlack;
-  lds_i* s_in = (lds_i*)tail;
-  lds_f* s_keep = tail + LP;
-  lds_i* s_pid = (lds_i*)(tail + 2 * LP);
-  lds_i* s_nid = (lds_i*)(tail + 3 * LP);
-  lds_f* s_misc = tail + 4 * LP;          // 64 floats
-  lds_f* s_ln = s_misc + 64;              // LayerNorm parameter cache
-  {
-    const int total = (int)fwd_lds_floats(g, ly.n_blocks);
-    for (int i = tid; i < total; i += nthr) lds0[i] = 0.f;
-  }
-  __syncthreads();
-  fill_ln_cache(s_ln, a.dense, ly);
-
-  const float* P = a.dense;
-  const float* table = a.table;
-  const int kind = ly.kind;
-  const bool is_sas = kind == SRFRD_SASREC;
-  const bool has_fake = kind == SRFRD_SRFR || kind == SRFRD_SRFRN;
-  const bool is_srfu = kind >= SRFRD_SRFU_B;
-  const int di = ly.d_item, dfk = ly.d_fake, dout = ly.d_out;
-  const float sqrtD = sqrtf((float)di);
-  const float qscale = a.qscale;
-  const uint32_t seed = a.seed_dev ? *a.seed_dev : a.seed;
-  const int B = a.B;
-  // packed weight of matrix `mat` (block*6 + {Wq,Wk,Wv,Wo,W1,W2}; n_blocks*6 = last_conv); form 0: x W^T, 1: dy W
-  auto pk = [&](int mat, int form) {
-    return PackedB{reinterpret_cast<const float4*>(a.packed) + ((int64_t)mat * 2 + form) * (kPackFloats / 4)};
-  };
-
-  STAMP_INIT
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const int64_t rowbase = (int64_t)b * L;
-    const uint32_t seq = (uint32_t)(a.seq0 + b);
-    for (int t = tid; t < LP; t += nthr) {
-      const int id = t < L ? (int)a.in_ids[rowbase + t] : 0;
-      s_in[t] = id;
-      s_keep[t] = id != 0 ? 1.f : 0.f;
-      s_pid[t] = (t < L && a.pos_ids) ? (int)a.pos_ids[rowbase + t] : 0;
-      s_nid[t] = (t < L && a.neg_ids) ? (int)a.neg_ids[rowbase + t] : 0;
-    }
-    if (is_srfu && wave == 0) {
-      const int lab = user_label_wave(kind, a.fk_ids ? a.fk_ids + rowbase : nullptr, L, ly.n_labels);
-      if (lane == 0) ((lds_i*)s_misc)[0] = lab;
-    }
-    __syncthreads();
-
-    // ---- embedding: gather + position (+ side channel) + pad mask          
-    {
-      const DropSite dsE = drop_site(a.drop_on && is_sas, seed, SITE_EMB, seq, a.drop_thr, a.drop_scale);
-      const int lab = is_srfu ? ((lds_i*)s_misc)[0] : 0;
-      const int q = tid & 3;
-      for (int t = tid >> 2; t < L; t += nthr >> 2) {                  // one DPP quad per position
-        const int id = s_in[t];
-        const float keep = s_keep[t];
-        const int f = (has_fake && a.fk_ids) ? (int)a.fk_ids[rowbase + t] : 0;
-#pragma unroll
-        for (int j = 0; j < kQC; ++j) {
-          const int c = q + 4 * j;
-          if (c < D) {
-            float v;
-            if (has_fake) {
-              if (c < di) v = table[(int64_t)id * di + c] + P[ly.off_pos + t * di + c];
-              else v = P[ly.off_side + f * dfk + (c - di)];
-            } else {
-              v = table[(int64_t)id * di + c];
-              if (is_sas) v *= sqrtD;
-              v += P[ly.off_pos + t * di + c];
-              if (is_srfu) v += P[ly.off_side + lab * D + c];
-              if (is_sas) v *= drop_mul(dsE, t, c);
-            }
-            v *= keep;
-            bXS[t * DS + c] = v;
-            if (a.save_x) a.save_x[(rowbase + t) * D + c] = v;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    tap(a, b, 0, bXS, L, D, DS);
-
-    for (int i = 0; i < ly.n_blocks; ++i) {
-      const BlkOff o = blk_off(ly.blk0 + i * ly.blk_stride, D);
-      const int tb = 1 + 8 * i;
-      launder(bXS); launder(bQN); launder(bQ); launder(bK); launder(bV);
-      // weight fragments are requested one phase ahead of the GEMM that consumes them
-      const WFrag wq = load_wfrag(pk(i * 6 + 0, 0), P + o.in_b, D, NT);
-      const WFrag wk = load_wfrag(pk(i * 6 + 1, 0), P + o.in_b + D, D, NT);
-      const WFrag wv = load_wfrag(pk(i * 6 + 2, 0), P + o.in_b + 2 * D, D, NT);
-      ln_rows(nw, bXS, bQN, L, DS, D, s_ln + (4 * i + 0) * 64, s_ln + (4 * i + 1) * 64);
-      __syncthreads();
-      tap(a, b, tb + 0, bQN, L, D, DS);
-      // q = (LN(x) Wq^T + bq) * sqrt(1/d_h);  k = x Wk^T + bk;  v = x Wv^T + bv
-      gemm_packed(nw, MT, NT, DK, Mat{bQN, DS}, wq, [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v * qscale; });
-      gemm_packed(nw, MT, NT, DK, Mat{bXS, DS}, wk, [&](int r, int c, float v) { if (c < D) bK[r * DS + c] = v; });
-      gemm_packed(nw, MT, NT, DK, Mat{bXS, DS}, wv, [&](int r, int c, float v) { if (c < D) bV[r * DS + c] = v; });
-      const WFrag wo = load_wfrag(pk(i * 6 + 3, 0), P + o.out_b, D, NT);
-      const WFrag w1 = load_wfrag(pk(i * 6 + 4, 0), P + o.c1_b, D, NT);
-      __syncthreads();
-      tap(a, b, tb + 1, bQ, L, D, DS);
-      tap(a, b, tb + 2, bK, L, D, DS);
-      tap(a, b, tb + 3, bV, L, D, DS);
-      // S = q k^T on the lower-triangular tiles (x is dead: S overlays it)
-      gemm_tiles<1>(nw, MT, MT, DK, Mat{bQ, DS}, MatT{bK, DS}, [&](int r, int c, float v) { bXS[r * SLD + c] = v; });
-      __syncthreads();
-      // causal softmax (+ attention dropout); keys j > r get exact zeros up to LP
-      {
-        const DropSite dsA = drop_site(a.drop_on, seed, site_attn(i), seq, a.drop_thr, a.drop_scale);
-        softmax_rows<true>(nw, bXS, L, SLD, LP, dsA);
-      }
-      __syncthreads();
-      tap(a, b, tb + 4, bXS, L, L, SLD);
-      // o = P v  (q is dead: o overlays it)
-      gemm_tiles<2>(nw, MT, NT, LP, Mat{bXS, SLD}, Mat{bV, DS}, [&](int r, int c, float v) { if (c < D) bQ[r * DS + c] = v; });
-      __syncthreads();
-      // h1 = LN(x) + (o Wo^T + bo)
-      gemm_packed(nw, MT, NT, DK, Mat{bQ, DS}, wo, [&](int r, int c, float v) {
-        if (c < D) {
-          const float h = bQN[r * DS + c] + v;
-          bXS[r * DS + c] = h;
-          if (a.save_h1 && r < L) a.save_h1[((int64_t)i * B * L + rowbase + r) * D + c] = h;
-        }
-      });
-      __syncthreads();
-      tap(a, b, tb + 5, bXS, L, D, DS);
-      ln_rows(nw, bXS, bQN, L, DS, D, s_ln + (4 * i + 2) * 64, s_ln + (4 * i + 3) * 64);
-      __syncthreads();
-      tap(a, b, tb + 6, bQN, L, D, DS);
-      // PW-FFN: y = (drop2(relu(drop1(h2 W1^T + b1)) W2^T + b2) + h2) * keep
-      const DropSite ds1 = drop_site(a.drop_on, seed, site_ffn1(i), seq, a.drop_thr, a.drop_scale);
-      const DropSite ds2 = drop_site(a.drop_on, seed, site_ffn2(i), seq, a.drop_thr, a.drop_scale);
-      const WFrag w2 = load_wfrag(pk(i * 6 + 5, 0), P + o.c2_b, D, NT);
-      gemm_packed(nw, MT, NT, DK, Mat{bQN, DS}, w1, [&](int r, int c, float v) {
-        if (c < D) bQ[r * DS + c] = fmaxf(v * drop_mul(ds1, r, c), 0.f);
-      });
-      __syncthreads();
-      gemm_packed(nw, MT, NT, DK, Mat{bQ, DS}, w2, [&](int r, int c, float v) {
-        if (c < D) {
-          const float y = (v * drop_mul(ds2, r, c) + bQN[r * DS + c]) * s_keep[r];
-          bXS[r * DS + c] = y;
-          if (a.save_x && r < L) a.save_x[((int64_t)(i + 1) * B * L + rowbase + r) * D + c] = y;
-        }
-      });
-      __syncthreads();
-      tap(a, b, tb + 7, bXS, L, D, DS);
-    }
-
-    // ---- head: (last_conv) -> last LayerNorm -> hidden, pos/neg logits, BCE partial sums
-    const lds_f* hin = bXS;
-    if (kind == SRFRD_SRFR) {
-      const WFrag wl = load_wfrag(pk(ly.n_blocks * 6, 0), P + ly.off_lc_b, di, (di + 15) >> 4);
-      gemm_packed(nw, MT, (di + 15) >> 4, DK, Mat{bXS, DS}, wl, [&](int r, int c, float v) { if (c < di) bQ[r * DS + c] = v; });
-      __syncthreads();
-      hin = bQ;
-    }
-    ln_rows(nw, hin, bQN, L, DS, dout, s_ln + (4 * ly.n_blocks) * 64, s_ln + (4 * ly.n_blocks + 1) * 64);
-    __syncthreads();
-    {
-      float sp = 0.f, sn = 0.f, cnt = 0.f;
-      const int q = tid & 3;
-      const bool srfrn = kind == SRFRD_SRFRN;
-      for (int t = tid >> 2; t < L; t += nthr >> 2) {                  // one DPP quad per position
-        const int pid = s_pid[t], nid = s_nid[t];
-        const int pf = (srfrn && a.pos_ids) ? (int)a.pos_fk[rowbase + t] : 0;
-        const int nf = (srfrn && a.neg_ids) ? (int)a.neg_fk[rowbase + t] : 0;
-        float ap = 0.f, an = 0.f;
-#pragma unroll
-        for (int j = 0; j < kQC; ++j) {
-          const int c = q + 4 * j;
-          if (c < dout) {
-            const float h = bQN[t * DS + c];
-            a.hidden[(rowbase + t) * dout + c] = h;
-            if (a.pos_ids) ap += h * (c < di ? table[(int64_t)pid * di + c] : P[ly.off_side + pf * dfk + (c - di)]);
-            if (a.neg_ids) an += h * (c < di ? table[(int64_t)nid * di + c] : P[ly.off_side + nf * dfk + (c - di)]);
-          }
-        }
-        const float pl = quad_sum(ap), nl = quad_sum(an);
-        if (q == 0) {
-          if (a.pos_ids) a.pos_logits[rowbase + t] = pl;
-          if (a.neg_ids) a.neg_logits[rowbase + t] = nl;
-          if (a.loss_part && pid != 0) {          // trainer.py:36-38: both terms indexed by pos != 0
-            sp += softplus_f(-pl);
-            sn += softplus_f(nl);
-            cnt += 1.f;
-          }
-        }
-      }
-      if (a.loss_part) {
-        sp = wave_sum(sp); sn = wave_sum(sn); cnt = wave_sum(cnt);
-        if (lane == 0) {
-          s_misc[8 + wave * 3 + 0] = sp;
-          s_misc[8 + wave * 3 + 1] = sn;
-          s_misc[8 + wave * 3 + 2] = cnt;
-        }
-        __syncthreads();
-        if (tid < 3) {
-          float s = 0.f;
-          for (int w = 0; w < nw; ++w) s += s_misc[8 + w * 3 + tid];
-          a.loss_part[(int64_t)b * 3 + tid] = s;
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
 // ================================================================================================
 // weight packing: canonical (N, K) row-major weights -> MFMA B-fragment order, both product forms
 // ================================================================================================
@@ -274,6 +45,19 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const srfrd_layout ly
 }  // namespace srfrd
 
 using namespace srfrd;
+
+extern "C" int srfrd_long_launch_fwd(const void* args, int grid, int threads, void* stream);   // srfrd_encoder_fwd_long.hip
+
+extern "C" int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64_t* fwd_floats, int64_t* bwd_floats) {
+  if (!lay || B <= 0 || L <= 0) return SRFRD_E_ARG;
+  const Geom g = make_geom(L, lay->D);
+  const int64_t f = fwd_lds_floats(g, lay->n_blocks), bw = bwd_lds_floats(g, lay->n_blocks);
+  int gf = num_cu() * 2;
+  if (gf > B) gf = B;
+  if (fwd_floats) *fwd_floats = f * 4 <= kLdsLimit ? 0 : ((f + 63) & ~63ll) * gf;
+  if (bwd_floats) *bwd_floats = bw * 4 <= kLdsLimit ? 0 : ((bw + 63) & ~63ll) * srfrd_bwd_grid(B);
+  return 0;
+}
 
 extern "C" int srfrd_lds_bytes(const srfrd_layout* lay, int L, int64_t* fwd_bytes, int64_t* bwd_bytes) {
   if (!lay || L <= 0) return SRFRD_E_ARG;
@@ -309,7 +93,8 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
                                  const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
                                  double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
                                  float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
-                                 float* loss_part, float* dbg, int dbg_seq, void* stream) {
+                                 float* loss_part, float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq,
+                                 void* stream) {
   EncArgs a = {};
   int rc = fill_args(a, lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
                      dropout_p, seed, seed_dev, seq_index0);
@@ -322,7 +107,15 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
   srfrd_debug_shape(lay, L, &a.dbg_slot, nullptr);
   const Geom g = make_geom(L, lay->D);
   const int64_t lds = fwd_lds_floats(g, lay->n_blocks) * 4;
-  if (lds > kLdsLimit) return SRFRD_E_UNSUPPORTED;
+  if (lds > kLdsLimit) {                       // long sequence: working set in the caller's global scratch
+    int grid = num_cu() * 2;
+    if (grid > B) grid = B;
+    const int64_t stride = (fwd_lds_floats(g, lay->n_blocks) + 63) & ~63ll;
+    if (!scratch || scratch_floats < stride * grid) return SRFRD_E_UNSUPPORTED;
+    a.scratch = scratch;
+    a.scratch_stride = stride;
+    return srfrd_long_launch_fwd(&a, grid, 256, stream);
+  }
   const int per_cu = (int)(kLdsLimit / lds) > 2 ? 2 : (int)(kLdsLimit / lds);
   int grid = num_cu() * (per_cu < 1 ? 1 : per_cu);
   if (grid > B) grid = B;

@@ -132,6 +132,7 @@ class _SRFRDBase(nn.Module):
         self._flat = None
         self._slots = None
         self._packed = None
+        self._scratch = None
 
     # ---- layout / flat storage
     @property
@@ -208,6 +209,15 @@ class _SRFRDBase(nn.Module):
                                             ptr(self._packed), _stream()), "srfrd_pack_weights")
         return self._packed
 
+    def _scratch_for(self, B, L, backward):
+        """global workspace for sequences whose working set does not fit LDS (None when it does)."""
+        need = _lib.scratch_floats(self.layout, B, L)[1 if backward else 0]
+        if need == 0:
+            return None, 0
+        if self._scratch is None or self._scratch.numel() < need or self._scratch.device != self._flat.device:
+            self._scratch = torch.empty(need, device=self._flat.device, dtype=torch.float32)
+        return self._scratch, need
+
     # ---- launches
     def _launch_fwd(self, inp, fk, pos, pfk, neg, nfk, dropout_p, seed, save, seq0=0, dbg=None, dbg_seq=0):
         lay, flat = self.layout, self._flat
@@ -219,11 +229,12 @@ class _SRFRDBase(nn.Module):
         sx = torch.empty(lay.n_blocks + 1, B, L, lay.D, device=dev, dtype=torch.float32) if save else None
         sh = torch.empty(lay.n_blocks, B, L, lay.D, device=dev, dtype=torch.float32) if save else None
         packed = self.pack_weights()          # parameters may have been stepped since the last call
+        scratch, n_scr = self._scratch_for(B, L, backward=False)
         check(_lib.lib().srfrd_encoder_fwd(
             C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(packed),
             ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
-            None, int(seq0), ptr(hidden), ptr(pl), ptr(nl), ptr(sx), ptr(sh), None, ptr(dbg), int(dbg_seq), _stream()),
-            "srfrd_encoder_fwd")
+            None, int(seq0), ptr(hidden), ptr(pl), ptr(nl), ptr(sx), ptr(sh), None, ptr(scratch), n_scr, ptr(dbg),
+            int(dbg_seq), _stream()), "srfrd_encoder_fwd")
         return {"hidden": hidden, "pos_logits": pl, "neg_logits": nl, "save_x": sx, "save_h1": sh}
 
     def _launch_bwd(self, inp, fk, pos, pfk, neg, nfk, dropout_p, seed, out, d_hidden, d_pl, d_nl, seq0=0,
@@ -234,12 +245,13 @@ class _SRFRDBase(nn.Module):
         gflat = torch.zeros(self.n_flat, device=dev, dtype=torch.float32)
         n_slabs = _lib.lib().srfrd_bwd_grid(B)
         slabs = torch.empty(n_slabs, lay.n_dense, device=dev, dtype=torch.float32)
+        scratch, n_scr = self._scratch_for(B, L, backward=True)
         check(_lib.lib().srfrd_encoder_bwd(
             C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(self._packed),
             ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
             None, int(seq0), ptr(out["hidden"]), ptr(out["pos_logits"]), ptr(out["neg_logits"]), ptr(out["save_x"]),
-            ptr(out["save_h1"]), ptr(d_hidden), ptr(d_pl), ptr(d_nl), 0, ptr(gflat), ptr(slabs), ptr(dbg), int(dbg_seq),
-            _stream()), "srfrd_encoder_bwd")
+            ptr(out["save_h1"]), ptr(d_hidden), ptr(d_pl), ptr(d_nl), 0, ptr(gflat), ptr(slabs), ptr(scratch), n_scr,
+            ptr(dbg), int(dbg_seq), _stream()), "srfrd_encoder_bwd")
         check(_lib.lib().srfrd_reduce_dense(ptr(slabs), n_slabs, lay.n_dense,
                                             C.c_void_p(gflat.data_ptr() + 4 * self.n_table_pad), None, B, None, _stream()),
               "srfrd_reduce_dense")

@@ -53,9 +53,9 @@ class FusedTrainer:
         self.flat = model._flat
         dev = self.flat.device
         self.B, self.L = int(batch_size), int(seq_len or self.lay.max_len)
-        fwd_b, bwd_b = _lib.lds_bytes(self.lay, self.L)
-        if fwd_b == 0 or bwd_b == 0:
-            raise NotImplementedError(f"seq_len {self.L} at width {self.lay.D} does not fit the LDS-resident train kernels")
+        n_f, n_b = _lib.scratch_floats(self.lay, self.B, self.L)      # 0 when the working set fits LDS
+        self.scratch = torch.empty(max(n_f, n_b), device=dev, dtype=torch.float32) if max(n_f, n_b) else None
+        self.n_scratch = max(n_f, n_b)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -102,11 +102,12 @@ class FusedTrainer:
         check(L_.srfrd_encoder_fwd(C.byref(lay), ptr(self.flat), self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
                                    ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
                                    ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.loss_part),
-                                   None, 0, st), "srfrd_encoder_fwd")
+                                   ptr(self.scratch), self.n_scratch, None, 0, st), "srfrd_encoder_fwd")
         check(L_.srfrd_encoder_bwd(C.byref(lay), ptr(self.flat), self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
                                    ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
                                    ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), None, None, None, 1,
-                                   ptr(self.grad), ptr(self.slabs), None, 0, st), "srfrd_encoder_bwd")
+                                   ptr(self.grad), ptr(self.slabs), ptr(self.scratch), self.n_scratch, None, 0, st),
+              "srfrd_encoder_bwd")
         check(L_.srfrd_reduce_dense(ptr(self.slabs), self.n_slabs, lay.n_dense, self._dense_ptr(self.grad),
                                     ptr(self.loss_part), self.B, C.c_void_p(self.grad.data_ptr() + 4 * self.n_flat), st),
               "srfrd_reduce_dense")

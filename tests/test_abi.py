@@ -48,6 +48,9 @@ def test_lds_capability_query():
     f100, b100 = _lib.lds_bytes(lay, 100)
     assert f100 > 0 and b100 == 0                         # round 1: backward is LDS-resident up to 64 positions
     assert _lib.lds_bytes(lay, 200) == (0, 0)
+    assert _lib.scratch_floats(lay, 512, 50) == (0, 0)             # LDS-resident
+    f200, b200 = _lib.scratch_floats(lay, 512, 200)                 # long-sequence build: global scratch per workgroup
+    assert f200 > 0 and b200 > 0 and _lib.scratch_floats(lay, 512, 100)[1] > 0
     assert _lib.lib().srfrd_bwd_grid(7) == 7
     assert _lib.lib().srfrd_packed_floats(C.byref(lay)) == (2 * 6 + 1) * 2 * 4096
 
@@ -59,4 +62,4 @@ def test_argument_errors_are_codes_not_crashes():
     assert lib.srfrd_eval_rank(None, 4, 4, None, None, None) == -1
     assert lib.srfrd_topk_workspace_bytes(0, 10, 100) == 0
     lay = _lib.make_layout("SASRec", 100, 20, 50, 0, 0, 2, 1)
-    assert lib.srfrd_encoder_fwd(C.byref(lay), *([None] * 9), 4, 20, 0.0, 0, None, 0, *([None] * 7), 0, None) == -1
+    assert lib.srfrd_encoder_fwd(C.byref(lay), *([None] * 9), 4, 20, 0.0, 0, None, 0, *([None] * 7), 0, None, 0, None) == -1

@@ -1,0 +1,71 @@
+"""-m gpu: sequences too long for the LDS-resident kernels (C4: seq_len 100, C5: seq_len 200) run the global-scratch
+build of the same kernel sources; parity against the CPU oracle at 1e-4, plus C4-shaped training parity."""
+import pytest
+import torch
+
+from oracle import srfrd_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _setup(kind, L, B=6, I=300, seed=0):
+    import srfrd_amd
+    from tests.gpu_util import build_model, random_sd
+    if kind == "SASRec":
+        cfg = O.Cfg(kind, I, L, 50)
+    elif kind == "SRFRN":
+        cfg = O.Cfg(kind, I, L, 45, d_fake=5)
+    else:
+        cfg = O.Cfg(kind, I, L, 50, n_labels=3)
+    sd = random_sd(cfg, seed)
+    model = build_model(cfg, sd)
+    batch = srfrd_amd.synthetic_batch(I, L, B, seed=5, device="cpu")[1:]
+    return cfg, sd, model, batch
+
+
+@pytest.mark.parametrize("kind,L", [("SASRec", 100), ("SRFRN", 100), ("SRFU_B", 128), ("SASRec", 200)])
+def test_long_forward_matches_oracle(kind, L):
+    from srfrd_amd import _lib
+    from tests.gpu_util import cuda, maxerr
+    cfg, sd, model, batch = _setup(kind, L)
+    if L > 112:
+        assert _lib.lds_bytes(model.layout, L)[0] == 0           # really the scratch build
+    model.eval()
+    with torch.no_grad():
+        h, pl, nl = model(None, *cuda(*batch))
+    ho, plo, nlo = O.forward(cfg, sd, *batch)
+    assert maxerr(h, ho) < TOL and maxerr(pl, plo) < TOL and maxerr(nl, nlo) < TOL
+
+
+@pytest.mark.parametrize("kind,L", [("SASRec", 100), ("SRFRN", 100), ("SASRec", 200)])
+def test_c4_c5_length_training_matches_oracle(kind, L):
+    """seq_len 100 / 200 (BASELINE configs[3] / [4] geometry): gradients, loss and two fused Adam steps vs the oracle."""
+    import srfrd_amd
+    from srfrd_amd import _lib
+    from tests.gpu_util import cuda, maxerr
+    from tests.helpers import drop_kbias
+    cfg, sd, model, batch = _setup(kind, L, B=5)
+    assert _lib.lds_bytes(model.layout, L)[1] == 0 and _lib.scratch_floats(model.layout, 5, L)[1] > 0
+    model.train()                                            # dropout_rate = 0 in cfg
+    loss_o, grads_o, *_ = O.grads_of(cfg, sd, batch)
+    seq, rsq, pos, prs, neg, nrs = cuda(*batch)
+    h, pl, nl = model(None, seq, rsq, pos, prs, neg, nrs)
+    idx = torch.where(pos != 0)
+    crit = torch.nn.BCEWithLogitsLoss()
+    loss = crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_o)) < TOL
+    for k, p in model.named_parameters():
+        assert maxerr(p.grad, grads_o[k]) < TOL, k
+    # fused trainer on the same shape
+    model.zero_grad(set_to_none=True)
+    tr = srfrd_amd.FusedTrainer(model, 5, L, use_graph=False)
+    opt = O.Adam(sd)
+    for step in range(2):
+        l = tr.step(None, seq, rsq, pos, prs, neg, nrs)
+        lo = O.train_step(cfg, sd, opt, batch, train=False)
+        assert abs(float(l.cpu()) - float(lo)) < TOL
+    msd = model.state_dict()
+    for k in sd:
+        assert maxerr(drop_kbias(k, msd[k].cpu(), cfg.D), drop_kbias(k, sd[k], cfg.D)) < 3e-4, k
