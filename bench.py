@@ -20,6 +20,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 C2 = dict(kind="SASRec", n_items=50_000, seq_len=50, batch=512, hidden=50, blocks=2, heads=1, dropout=0.5)
+# the other BASELINE.json configs: parity-test cases, selectable for exploration only (--workload); never the default
+WORKLOADS = {
+    "C2": C2,
+    "C3": dict(kind="SRFRN", n_items=50_000, seq_len=50, batch=512, hidden=45, fake=5, blocks=2, heads=1, dropout=0.5),
+    "C3u": dict(kind="SRFU_B", n_items=50_000, seq_len=50, batch=512, hidden=50, labels=3, blocks=2, heads=1, dropout=0.5),
+    "C4": dict(kind="SASRec", n_items=200_000, seq_len=100, batch=512, hidden=50, blocks=2, heads=1, dropout=0.5),
+    "C5": dict(kind="SASRec", n_items=1_000_000, seq_len=200, batch=512, hidden=50, blocks=2, heads=1, dropout=0.5),
+}
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (matrix) dense
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 
@@ -129,6 +137,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="exploration only; the contract line is C2")
+    ap.add_argument("--predict", action="store_true", help="time forward + full-catalog top-10 instead of the train step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,14 +154,21 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import srfrd_amd
-    cfg = C2
+    cfg = WORKLOADS[args.workload]
     torch.manual_seed(0)                      # identical init on every rank (replicated parameters)
-    model = srfrd_amd.SASRec(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
+    if cfg["kind"] == "SASRec":
+        model = srfrd_amd.SASRec(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
+    elif cfg["kind"] == "SRFRN":
+        model = srfrd_amd.SRFRN(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["fake"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
+    else:
+        model = srfrd_amd.SRFU_B(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["labels"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
     for _, p in model.named_parameters():     # reference trainer.py:364-369
         if p.dim() >= 2:
             torch.nn.init.xavier_normal_(p.data)
     model = model.to(dev).train()
     B, L = cfg["batch"], cfg["seq_len"]
+    if args.predict or args.workload != "C2":
+        return explore(args, cfg, model, dev, rank)
     tr = srfrd_amd.FusedTrainer(model, B, L, lr=1e-3, betas=(0.9, 0.98), seed=42, use_graph=not args.no_graph)
     batches = [srfrd_amd.synthetic_batch(cfg["n_items"], L, B, seed=1, index=i, rank=rank, device=dev, packed=True)[1]
                for i in range(8)]
@@ -218,6 +235,30 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def explore(args, cfg, model, dev, rank):
+    """Non-contract measurements of the other BASELINE configs (train step, or forward + full-catalog top-10)."""
+    import srfrd_amd
+    B, L = cfg["batch"], cfg["seq_len"]
+    u, seq, rsq, pos, prs, neg, nrs = srfrd_amd.synthetic_batch(cfg["n_items"], L, B, seed=1, rank=rank, device=dev)
+    if args.predict:
+        model.eval()
+        fn = lambda: model.topk(u, seq, rsq, k=10)
+    else:
+        tr = srfrd_amd.FusedTrainer(model, B, L, use_graph=not args.no_graph)
+        fn = lambda: tr.step(u, seq, rsq, pos, prs, neg, nrs)
+    for _ in range(args.warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fn()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({"workload": args.workload, "mode": "predict_top10" if args.predict else "train_step",
+                      "kind": cfg["kind"], "sequences_per_s": B * args.steps / el, "ms_per_step": el / args.steps * 1e3,
+                      "batch": B, "seq_len": L, "n_items": cfg["n_items"], "contract_line": False}), flush=True)
 
 
 def time_kernels(tr, batches, steps):
