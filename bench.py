@@ -146,12 +146,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()
+    local = local % max(n_dev, 1)             # rehearsal of the multi-rank path on a one-GPU box (SRFRD_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SRFRD_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import srfrd_amd
     cfg = WORKLOADS[args.workload]
@@ -197,7 +203,6 @@ def main():
     log(f"timed region: {elapsed:.4f} s for {args.steps} steps, loss {loss:.5f}")
 
     # ---- dominant-kernel timing: HIP events around each launch of the same K steps, eager, on the launch stream
-    import ctypes as Cc
     kt = {"srfrd_encoder_fwd": 0.0, "srfrd_encoder_bwd": 0.0, "srfrd_adam_step": 0.0}
     if rank == 0:
         kt = time_kernels(tr, batches, min(args.steps, 50))
@@ -290,10 +295,7 @@ def time_kernels(tr, batches, steps):
             tr.ids.copy_(batches[i % 8], non_blocking=True)
             ev[i][0].record()
             tr._enqueue_compute()
-            from srfrd_amd.trainer import flat_allreduce
-            if tr.world > 1:
-                flat_allreduce(tr.grad, tr.group)
-            tr._enqueue_update()
+            tr._enqueue_update()          # rank-0-only pass: NO collective here (the other ranks are not in this loop)
         torch.cuda.synchronize()
     finally:
         for n in names:

@@ -135,16 +135,17 @@ class FusedTrainer:
         for dst, src in zip((self.flat, self.m, self.v, self.state, self.grad), snap):
             dst.copy_(src)
         self.model.pack_weights()             # the warm-up step re-packed the stepped weights: restore that too
+        # thread_local capture mode: a collective backend's watchdog thread may touch the HIP runtime while we capture
         if self.world == 1:
             self._graph_a = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_a):
+            with torch.cuda.graph(self._graph_a, capture_error_mode="thread_local"):
                 self._enqueue_compute()
                 self._enqueue_update()
         else:
             self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_a):
+            with torch.cuda.graph(self._graph_a, capture_error_mode="thread_local"):
                 self._enqueue_compute()
-            with torch.cuda.graph(self._graph_b):
+            with torch.cuda.graph(self._graph_b, capture_error_mode="thread_local"):
                 self._enqueue_update()
 
     # ---- public -------------------------------------------------------------------------------
