@@ -127,3 +127,31 @@ def test_dropout_statistics_and_backward_consistency():
     b = model._launch_fwd(*ids, 0.5, 11, save=False)["hidden"]
     c = model._launch_fwd(*ids, 0.5, 12, save=False)["hidden"]
     assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+@pytest.mark.parametrize("kind,d_item,d_fake,L", [("SASRec", 64, 0, 20), ("SRFR", 43, 5, 33), ("SRFRN", 50, 10, 17),
+                                                  ("SRFU_R", 32, 0, 48), ("SASRec", 16, 0, 5)])
+def test_other_widths_and_lengths_match_oracle(kind, d_item, d_fake, L):
+    """Generic (run-time geometry) kernels: widths that are / are not multiples of 16 (bias-gradient folding on and off),
+    the reference constructors' default 50 + 10, odd lengths; forward, loss and every gradient vs the oracle."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, maxerr, random_sd
+    I, B = 200, 7
+    if kind == "SASRec":
+        cfg = O.Cfg(kind, I, L, d_item)
+    elif kind in ("SRFR", "SRFRN"):
+        cfg = O.Cfg(kind, I, L, d_item, d_fake=d_fake)
+    else:
+        cfg = O.Cfg(kind, I, L, d_item, n_labels=11)
+    sd = random_sd(cfg, 3)
+    model = build_model(cfg, sd).train()
+    batch = srfrd_amd.synthetic_batch(I, L, B, seed=9, device="cpu", min_len=1)[1:]
+    loss_o, grads_o, h_o, pl_o, nl_o = O.grads_of(cfg, sd, batch)
+    seq, rsq, pos, prs, neg, nrs = cuda(*batch)
+    h, pl, nl = model(None, seq, rsq, pos, prs, neg, nrs)
+    assert maxerr(h, h_o) < TOL and maxerr(pl, pl_o) < TOL and maxerr(nl, nl_o) < TOL
+    loss = _loss(pl, nl, pos)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_o)) < TOL
+    for k, p in model.named_parameters():
+        assert maxerr(p.grad, grads_o[k]) < TOL, k
