@@ -206,6 +206,19 @@ int srfrd_logits_topk(const srfrd_layout* lay, const float* item_table, const fl
  * metric_acc[0] += [rank<10] / log2(rank+2), metric_acc[1] += [rank<10], metric_acc[2] += 1 (double[3]). */
 int srfrd_eval_rank(const float* logits, int B, int n_cand, int32_t* rank, double* metric_acc, void* stream);
 
+/*
+ * Device-side batch sampler with the layout and semantics of reference utils.py:21-57 (sample_function_fr /
+ * WarpSampler_fr): per sampled user (uniform among users with > 1 interaction) the most recent `L` training items
+ * left-padded with 0, pos[t] = the next item, neg[t] = a uniform item outside the user's history wherever pos[t] != 0,
+ * rsq / prs the fake(1)/real(2) ids, nrs = 1 where set.  Histories are CSR over user ids 0..usernum:
+ * user_ptr int64 (usernum + 2), items / reviews int32.  out_packed int64 (6, B, L) = [seq, rsq, pos, prs, neg, nrs].
+ * Randomness: counter hash of (seed, batch_index, row, position, try) - reproducible, unlike the reference's
+ * unseeded worker processes (utils.py:79).
+ */
+int srfrd_sample_batch(const int64_t* user_ptr, const int32_t* items, const int32_t* reviews, int usernum, int itemnum,
+                       int B, int L, uint32_t seed, uint32_t batch_index, int64_t* out_user, int64_t* out_packed,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

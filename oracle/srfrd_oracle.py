@@ -385,3 +385,79 @@ class TorchStep:
         loss.backward()
         self.opt.step()
         return loss
+
+
+# ----------------------------------------------------------------------------------------------
+# dataset side: loop restatements used to check srfrd_amd/dataset.py and the device sampler
+# ----------------------------------------------------------------------------------------------
+def partition_rows(rows, is_valid=False):
+    """reference utils.py:92-139 (df_data_partition) on (user, item, 'fake'|other) rows in file order."""
+    from collections import defaultdict
+    usernum = itemnum = 0
+    User, Rev = defaultdict(list), defaultdict(list)
+    final_idx = -2 if is_valid else -1
+    for u, i, f in rows:
+        usernum, itemnum = max(u, usernum), max(i, itemnum)
+        User[u].append(i)
+        Rev[u].append(1 if f == "fake" else 2)
+    train = {"item_ids": {}, "review_ids": {}}
+    test = {"item_ids": {}, "review_ids": {}}
+    for u in User:
+        if len(User[u]) < 2:
+            train["item_ids"][u], train["review_ids"][u] = User[u], Rev[u]
+            test["item_ids"][u], test["review_ids"][u] = [], []
+        else:
+            train["item_ids"][u], train["review_ids"][u] = User[u][:final_idx], Rev[u][:final_idx]
+            test["item_ids"][u], test["review_ids"][u] = [User[u][final_idx]], [Rev[u][final_idx]]
+    return train, test, usernum, itemnum
+
+
+def _samp_rnd(seed, batch, b, t, k):
+    with np.errstate(over="ignore"):
+        h = _fmix32(np.array([(seed & 0xFFFFFFFF) ^ ((batch * 0x9E3779B9) & 0xFFFFFFFF)], dtype=np.uint32))
+        h = _fmix32((h + np.uint32(b)).astype(np.uint32))
+        h = _fmix32(h ^ np.uint32((t * 4096 + k) & 0xFFFFFFFF))
+    return int(h[0])
+
+
+def sample_batch_ref(train_items, train_reviews, usernum, itemnum, B, L, seed, batch):
+    """reference utils.py:21-57 (sample_function_fr) with the device sampler's counter RNG: per row a user with more
+    than one interaction, sequences filled from the end, one negative outside the user's items per real position.
+    train_items / train_reviews: {user: list}.  -> (user (B,), packed (6,B,L)) int64 numpy."""
+    user = np.zeros(B, np.int64)
+    out = np.zeros((6, B, L), np.int64)
+    for b in range(B):
+        u = 1
+        for k in range(4096):
+            u = 1 + ((_samp_rnd(seed, batch, b, 0xFFFFF, k) * usernum) >> 32)
+            if len(train_items.get(u, [])) > 1:
+                break
+        user[b] = u
+        items, revs = train_items[u], train_reviews[u]
+        ts = set(items)
+        nxt, nxtr = items[-1], revs[-1]
+        idx = L - 1
+        for i, r in zip(reversed(items[:-1]), reversed(revs[:-1])):
+            out[0, b, idx], out[2, b, idx] = i, nxt
+            out[1, b, idx], out[3, b, idx] = r, nxtr
+            out[5, b, idx] = 1
+            cand = 1
+            for k in range(256):
+                cand = 1 + ((_samp_rnd(seed, batch, b, idx, k) * itemnum) >> 32)
+                if cand not in ts:
+                    break
+            out[4, b, idx] = cand
+            nxt, nxtr = i, r
+            idx -= 1
+            if idx == -1:
+                break
+    return user, out
+
+
+def window_labels_ref(rsq_row):
+    """reference utils.py:604-626 on one padded review window -> (binary, frequency, ratio)."""
+    n1 = int(np.count_nonzero(np.asarray(rsq_row) == 1))
+    n2 = int(np.count_nonzero(np.asarray(rsq_row) == 2))
+    binary = 1 if n1 > n2 else 2
+    ratio = int(np.floor(n1 / (n1 + n2) * 10)) if (n1 + n2) else 0
+    return binary, n1, ratio

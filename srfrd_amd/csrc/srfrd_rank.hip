@@ -271,3 +271,77 @@ extern "C" int srfrd_eval_rank(const float* logits, int B, int n_cand, int32_t* 
   hipLaunchKernelGGL(eval_rank_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, B, n_cand, rank, metric_acc);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// device-side batch sampler: the layout and semantics of reference utils.py:21-57 (sample_function_fr) with a
+// counter-based RNG, one wave per sampled user.  Histories arrive as CSR over user ids 0..usernum.
+// ---------------------------------------------------------------------------------------------
+namespace srfrd {
+
+__device__ __forceinline__ uint32_t samp_rnd(uint32_t seed, uint32_t batch, uint32_t b, uint32_t t, uint32_t k) {
+  return fmix32(fmix32(fmix32(seed ^ (batch * 0x9E3779B9u)) + b) ^ (t * 4096u + k));
+}
+__device__ __forceinline__ int samp_range(uint32_t r, int n) {      // uniform integer in [0, n)
+  return (int)(((unsigned long long)r * (unsigned long long)n) >> 32);
+}
+
+__global__ void __launch_bounds__(256) sample_batch_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ items,
+                                                          const int32_t* __restrict__ reviews, int usernum, int itemnum,
+                                                          int B, int L, uint32_t seed, uint32_t batch,
+                                                          int64_t* __restrict__ out_user, int64_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  // user with more than one interaction (utils.py:24-25): rejection, every lane draws the same stream
+  int u = 1, n = 0;
+  int64_t p0 = 0;
+  for (int k = 0; k < 4096; ++k) {
+    u = 1 + samp_range(samp_rnd(seed, batch, (uint32_t)b, 0xFFFFFu, (uint32_t)k), usernum);
+    p0 = ptr[u];
+    n = (int)(ptr[u + 1] - p0);
+    if (n > 1) break;
+  }
+  if (lane == 0) out_user[b] = u;
+  const int32_t* it = items + p0;
+  const int32_t* rv = reviews + p0;
+  const int64_t BL = (int64_t)B * L;
+  int64_t* seq = out + 0 * BL + (int64_t)b * L;
+  int64_t* rsq = out + 1 * BL + (int64_t)b * L;
+  int64_t* pos = out + 2 * BL + (int64_t)b * L;
+  int64_t* prs = out + 3 * BL + (int64_t)b * L;
+  int64_t* neg = out + 4 * BL + (int64_t)b * L;
+  int64_t* nrs = out + 5 * BL + (int64_t)b * L;
+  const int m = n > 1 ? min(n - 1, L) : 0;            // filled positions (most recent last)
+  for (int j = lane; j < L; j += 64) {
+    const int idx = L - 1 - j;
+    if (j < m) {
+      seq[idx] = it[n - 2 - j];
+      pos[idx] = it[n - 1 - j];
+      rsq[idx] = rv[n - 2 - j];
+      prs[idx] = rv[n - 1 - j];
+      nrs[idx] = 1;                                     // np.random.randint(1, 2) == 1 (utils.py:52)
+      int cand = 1;
+      for (int k = 0; k < 256; ++k) {                   // random_neq (utils.py:14-19): not among the user's items
+        cand = 1 + samp_range(samp_rnd(seed, batch, (uint32_t)b, (uint32_t)idx, (uint32_t)k), itemnum);
+        bool clash = false;
+        for (int q = 0; q < n; ++q) clash |= (it[q] == cand);
+        if (!clash) break;
+      }
+      neg[idx] = cand;
+    } else {
+      seq[idx] = 0; pos[idx] = 0; rsq[idx] = 0; prs[idx] = 0; neg[idx] = 0; nrs[idx] = 0;
+    }
+  }
+}
+
+}  // namespace srfrd
+
+extern "C" int srfrd_sample_batch(const int64_t* user_ptr, const int32_t* items, const int32_t* reviews, int usernum,
+                                  int itemnum, int B, int L, uint32_t seed, uint32_t batch_index, int64_t* out_user,
+                                  int64_t* out_packed, void* stream) {
+  if (!user_ptr || !items || !reviews || !out_user || !out_packed || usernum < 1 || itemnum < 1 || B <= 0 || L <= 0)
+    return SRFRD_E_ARG;
+  hipLaunchKernelGGL(srfrd::sample_batch_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, user_ptr, items,
+                     reviews, usernum, itemnum, B, L, seed, batch_index, out_user, out_packed);
+  return (int)hipGetLastError();
+}

@@ -108,3 +108,14 @@ def test_fused_trainer_rejects_l2():
     m = srfrd_amd.SASRec(10, 5, 50, 0.0, 1, 1, "cpu")
     with pytest.raises(NotImplementedError):
         srfrd_amd.FusedTrainer(m, 4, 5, l2_emb=0.1)
+
+
+def test_reference_checkpoint_roundtrip(tmp_path):
+    """a reference-format checkpoint (torch.save of the state_dict, trainer.py:409-411) loads strictly, safely."""
+    g, sd, _ = load_golden("SRFU_R")
+    path = tmp_path / "SRFR_3.pt"
+    torch.save(sd, path)
+    m = _build("SRFU_R", golden_cfg("SRFU_R"))
+    srfrd_amd.load_reference_checkpoint(m, str(path))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k])
