@@ -90,7 +90,7 @@ __host__ __device__ __forceinline__ int64_t fwd_lds_floats(const Geom& g, int n_
   return (int64_t)imax(g.LP * g.DS, g.LP * g.SLD) + 4ll * g.LP * g.DS + kSlack + 4ll * g.LP + 64 + ln_cache_floats(n_blocks);
 }
 __host__ __device__ __forceinline__ int64_t bwd_lds_floats(const Geom& g, int n_blocks) {
-  return 8ll * g.LP * g.DS + 2ll * imax(g.LP * g.SLD, g.LP * g.DS) + kSlack + 10ll * g.LP + 64 + 2ll * ln_cache_floats(n_blocks);
+  return 8ll * g.LP * g.DS + 2ll * imax(g.LP * g.SLD, g.LP * g.DS) + 2 * kSlack + 10ll * g.LP + 64 + 2ll * ln_cache_floats(n_blocks);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -30,6 +30,8 @@ struct EncArgs {
   // SRFRD_BUF_GLOBAL build only: per-workgroup working-set scratch (floats) in global memory
   float* scratch;
   int64_t scratch_stride;
+  int lds_floats;      // dynamic LDS (floats) the long build may carve from before falling back to `scratch`
+  int carve_mode;      // which buffers get the LDS share first (0: score matrices, 1: activation matrices)
   // debug taps
   float* dbg;
   int dbg_seq;

@@ -42,7 +42,7 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_tabl
   const int64_t lds = bwd_lds_floats(g, lay->n_blocks) * 4;
   const int grid = srfrd_bwd_grid(B);
   if (lds > kLdsLimit) {                       // long sequence: working set in the caller's global scratch
-    const int64_t stride = (bwd_lds_floats(g, lay->n_blocks) + 63) & ~63ll;
+    const int64_t stride = (bwd_lds_floats(g, lay->n_blocks) + 2 * kSlack + 63) & ~63ll;
     if (!scratch || scratch_floats < stride * grid) return SRFRD_E_UNSUPPORTED;
     a.scratch = scratch;
     a.scratch_stride = stride;

@@ -52,10 +52,10 @@ extern "C" int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64
   if (!lay || B <= 0 || L <= 0) return SRFRD_E_ARG;
   const Geom g = make_geom(L, lay->D);
   const int64_t f = fwd_lds_floats(g, lay->n_blocks), bw = bwd_lds_floats(g, lay->n_blocks);
-  int gf = num_cu() * 2;
+  int gf = num_cu();
   if (gf > B) gf = B;
-  if (fwd_floats) *fwd_floats = f * 4 <= kLdsLimit ? 0 : ((f + 63) & ~63ll) * gf;
-  if (bwd_floats) *bwd_floats = bw * 4 <= kLdsLimit ? 0 : ((bw + 63) & ~63ll) * srfrd_bwd_grid(B);
+  if (fwd_floats) *fwd_floats = f * 4 <= kLdsLimit ? 0 : ((f + 2 * kSlack + 63) & ~63ll) * gf;
+  if (bwd_floats) *bwd_floats = bw * 4 <= kLdsLimit ? 0 : ((bw + 2 * kSlack + 63) & ~63ll) * srfrd_bwd_grid(B);
   return 0;
 }
 
@@ -108,9 +108,9 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
   const Geom g = make_geom(L, lay->D);
   const int64_t lds = fwd_lds_floats(g, lay->n_blocks) * 4;
   if (lds > kLdsLimit) {                       // long sequence: working set in the caller's global scratch
-    int grid = num_cu() * 2;
+    int grid = num_cu();
     if (grid > B) grid = B;
-    const int64_t stride = (fwd_lds_floats(g, lay->n_blocks) + 63) & ~63ll;
+    const int64_t stride = (fwd_lds_floats(g, lay->n_blocks) + 2 * kSlack + 63) & ~63ll;
     if (!scratch || scratch_floats < stride * grid) return SRFRD_E_UNSUPPORTED;
     a.scratch = scratch;
     a.scratch_stride = stride;
