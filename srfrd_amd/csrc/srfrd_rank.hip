@@ -56,11 +56,18 @@ __global__ void __launch_bounds__(256) predict_logits_kernel(srfrd_layout ly, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// full-catalog top-k.  Stage 1: a workgroup stages a chunk of kChunk item rows in LDS once, then for every
-// 16-user tile forms the 16 x kChunk logits on the fp32 matrix cores and selects each user's k best of the
-// chunk (value desc, item id asc).  Stage 2 merges the per-chunk candidates.  Logits never reach HBM.
+// full-catalog top-k, exact, logits never written to HBM.  Threshold scheme in four launches:
+//   A  every (16-user tile, 512-item chunk) logits tile on the fp32 matrix cores -> per (user, chunk) MAXIMUM only
+//   T  per user: tau = k-th largest chunk maximum.  Each chunk maximum is a real score, so at least k scores are
+//      >= tau, i.e. tau is a lower bound on the k-th best score and every top-k item scores >= tau
+//   B  the same tiles again; scores >= tau are appended to the user's short candidate list (atomic cursor)
+//   S  per user: k rounds of (argmax, remove) over the candidates (value desc, item id asc => stable sort order)
+// A workgroup stages its chunk of item rows in LDS once and walks a strided subset of the user tiles, so small
+// catalogs still fill the chip.  If a user's candidates overflow the list (mass ties), the flag makes the host
+// launcher fall back to the per-chunk selection kernels below, which are exact for any input.
 // ---------------------------------------------------------------------------------------------
 constexpr int kChunk = 512;
+constexpr int kCandMax = 2048;
 
 struct Cand {
   float v;
@@ -69,6 +76,159 @@ struct Cand {
 
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
+struct TopkArgs {
+  srfrd_layout ly;
+  const float *table, *dense, *hidden;
+  const int64_t* user_label;
+  int B, L, exclude_pad, k, n_chunks, user_splits;
+  int64_t item_lo, item_hi;
+  float* cmax;          // (B, n_chunks)
+  float* tau;           // (B)
+  Cand* cand;           // (B, kCandMax)
+  int32_t* ccnt;        // (B) + 1 overflow flag at [B]
+};
+
+// stage a chunk of item rows and then, for this workgroup's user tiles, leave the 16 x kChunk logits tile in sS
+template <class F>
+__device__ __forceinline__ void topk_tiles(const TopkArgs& a, F&& per_tile) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, nw = blockDim.x >> 6;
+  const srfrd_layout& ly = a.ly;
+  const int di = ly.d_item, dout = ly.d_out, D = ly.D;
+  const bool srfrn = ly.kind == SRFRD_SRFRN;
+  const int DKi = (di + 3) & ~3, DSi = DKi + 2;
+  const int SLD = kChunk + 2;
+  lds_f* sE = (lds_f*)smem;
+  lds_f* sH = sE + kChunk * DSi;
+  lds_f* sS = sH + 16 * DSi;
+  lds_f* sF = sS + 16 * SLD;
+  const int chunk = blockIdx.x / a.user_splits, split = blockIdx.x - chunk * a.user_splits;
+  const int64_t i0 = a.item_lo + (int64_t)chunk * kChunk;
+  const int n_here = (int)((a.item_hi - i0) < kChunk ? (a.item_hi - i0) : kChunk);
+  for (int idx = tid; idx < kChunk * DSi; idx += blockDim.x) {
+    const int r = idx / DSi, c = idx - r * DSi;
+    sE[idx] = (r < n_here && c < di) ? a.table[(i0 + r) * di + c] : 0.f;
+  }
+  for (int u0 = split * 16; u0 < a.B; u0 += a.user_splits * 16) {
+    __syncthreads();
+    for (int idx = tid; idx < 16 * DSi; idx += blockDim.x) {
+      const int r = idx / DSi, c = idx - r * DSi;
+      sH[idx] = (u0 + r < a.B && c < di) ? a.hidden[((int64_t)(u0 + r) * a.L + (a.L - 1)) * dout + c] : 0.f;
+    }
+    if (srfrn && tid < 16) {
+      float s = 0.f;
+      if (u0 + tid < a.B) {
+        const int lab = (int)a.user_label[u0 + tid];
+        for (int c = di; c < D; ++c)
+          s += a.hidden[((int64_t)(u0 + tid) * a.L + (a.L - 1)) * dout + c] * a.dense[ly.off_side + lab * ly.d_fake + (c - di)];
+      }
+      sF[tid] = s;
+    }
+    __syncthreads();
+    gemm_tiles<0>(nw, 1, kChunk / 16, DKi, Mat{sH, DSi}, MatT{sE, DSi}, [&](int r, int c, float v) {
+      if (srfrn) v += sF[r];
+      const bool ok = c < n_here && !(a.exclude_pad && i0 + c == 0);
+      sS[r * SLD + c] = ok ? v : -INFINITY;
+    });
+    __syncthreads();
+    per_tile(u0, chunk, i0, sS, SLD);
+  }
+}
+
+__global__ void __launch_bounds__(256) topk_max_kernel(const TopkArgs a) {
+  topk_tiles(a, [&](int u0, int chunk, int64_t, lds_f* sS, int SLD) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int r = wave; r < 16; r += nw) {
+      float m = -INFINITY;
+      for (int j = lane; j < kChunk; j += 64) m = fmaxf(m, sS[r * SLD + j]);
+      m = wave_max(m);
+      if (lane == 0 && u0 + r < a.B) a.cmax[(int64_t)(u0 + r) * a.n_chunks + chunk] = m;
+    }
+  });
+}
+
+// tau[b] = k-th largest of cmax[b][:] (one wave per user; -inf if fewer than k finite maxima); also resets the cursor
+__global__ void __launch_bounds__(256) topk_tau_kernel(const TopkArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  float* row = a.cmax + (int64_t)b * a.n_chunks;
+  float tau = -INFINITY;
+  for (int r = 0; r < a.k; ++r) {
+    float bv = -INFINITY;
+    int bp = -1;
+    for (int j = lane; j < a.n_chunks; j += 64) {
+      const float v = row[j];
+      if (v > bv) { bv = v; bp = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int op = __shfl_xor(bp, o, 64);
+      if (ov > bv || (ov == bv && op >= 0 && (bp < 0 || op < bp))) { bv = ov; bp = op; }
+    }
+    if (bp < 0) { tau = -INFINITY; break; }       // fewer than k chunks hold a finite score: keep everything finite
+    tau = bv;
+    if (lane == 0) row[bp] = -INFINITY;
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) {
+    a.tau[b] = tau;
+    a.ccnt[b] = 0;
+    if (b == 0) a.ccnt[a.B] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) topk_collect_kernel(const TopkArgs a) {
+  topk_tiles(a, [&](int u0, int, int64_t i0, lds_f* sS, int SLD) {
+    for (int idx = threadIdx.x; idx < 16 * kChunk; idx += blockDim.x) {
+      const int r = idx / kChunk, c = idx - r * kChunk;
+      const int b = u0 + r;
+      if (b >= a.B) continue;
+      const float v = sS[r * SLD + c];
+      if (v != -INFINITY && v >= a.tau[b]) {
+        const int slot = atomicAdd(&a.ccnt[b], 1);
+        if (slot < kCandMax) a.cand[(int64_t)b * kCandMax + slot] = Cand{v, (int32_t)(i0 + c)};
+        else a.ccnt[a.B] = 1;                     // overflow: the launcher re-runs the exhaustive path
+      }
+    }
+  });
+}
+
+__global__ void __launch_bounds__(256) topk_select_kernel(const TopkArgs a, int64_t* __restrict__ topk_idx,
+                                                         float* __restrict__ topk_val) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  Cand* c = a.cand + (int64_t)b * kCandMax;
+  const int n = min(a.ccnt[b], kCandMax);
+  for (int r = 0; r < a.k; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7FFFFFFF, bp = -1;
+    for (int j = lane; j < n; j += 64) {
+      const float v = c[j].v;
+      const int id = c[j].i;
+      if (id >= 0 && better(v, id, bv, bi)) { bv = v; bi = id; bp = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      const int op = __shfl_xor(bp, o, 64);
+      if (op >= 0 && (bp < 0 || better(ov, oi, bv, bi))) { bv = ov; bi = oi; bp = op; }
+    }
+    if (lane == 0) {
+      topk_idx[(int64_t)b * a.k + r] = bp >= 0 ? bi : -1;
+      topk_val[(int64_t)b * a.k + r] = bp >= 0 ? bv : -INFINITY;
+      if (bp >= 0) c[bp].i = -1;
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- exhaustive fallback (exact for any input, e.g. every score tied): per-chunk selection + merge ----------
 // k rounds of (argmax, remove) over `n` scores in LDS by one wave; writes k candidates
 __device__ __forceinline__ void wave_select_topk(lds_f* sc, const int* ids, int n, int k, Cand* out) {
   const int lane = threadIdx.x & 63;
@@ -100,45 +260,14 @@ __global__ void __launch_bounds__(256) topk_stage1_kernel(srfrd_layout ly, const
                                                          const float* __restrict__ dense, const float* __restrict__ hidden,
                                                          int B, int L, int64_t item_lo, int64_t item_hi, int exclude_pad,
                                                          const int64_t* __restrict__ user_label, int k, int n_chunks,
-                                                         Cand* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int di = ly.d_item, dout = ly.d_out, D = ly.D;
-  const bool srfrn = ly.kind == SRFRD_SRFRN;
-  const int DKi = (di + 3) & ~3, DSi = DKi + 2;
-  const int SLD = kChunk + 2;
-  lds_f* sE = (lds_f*)smem;               // [kChunk][DSi] item rows of this chunk
-  lds_f* sH = sE + kChunk * DSi;          // [16][DSi]     last hidden state of 16 users (item part)
-  lds_f* sS = sH + 16 * DSi;              // [16][SLD]     logits
-  lds_f* sF = sS + 16 * SLD;              // [16]          SRFRN: <h[di:], fake_embed[label]> per user
-  const int chunk = blockIdx.x;
-  const int64_t i0 = item_lo + (int64_t)chunk * kChunk;
-  const int n_here = (int)((item_hi - i0) < kChunk ? (item_hi - i0) : kChunk);
-  for (int idx = tid; idx < kChunk * DSi; idx += blockDim.x) {
-    const int r = idx / DSi, c = idx - r * DSi;
-    sE[idx] = (r < n_here && c < di) ? table[(i0 + r) * di + c] : 0.f;
-  }
-  for (int u0 = 0; u0 < B; u0 += 16) {
-    __syncthreads();
-    for (int idx = tid; idx < 16 * DSi; idx += blockDim.x) {
-      const int r = idx / DSi, c = idx - r * DSi;
-      sH[idx] = (u0 + r < B && c < di) ? hidden[((int64_t)(u0 + r) * L + (L - 1)) * dout + c] : 0.f;
-    }
-    if (srfrn && tid < 16) {
-      float s = 0.f;
-      if (u0 + tid < B) {
-        const int lab = (int)user_label[u0 + tid];
-        for (int c = di; c < D; ++c) s += hidden[((int64_t)(u0 + tid) * L + (L - 1)) * dout + c] * dense[ly.off_side + lab * ly.d_fake + (c - di)];
-      }
-      sF[tid] = s;
-    }
-    __syncthreads();
-    gemm_tiles<0>(nw, 1, kChunk / 16, DKi, Mat{sH, DSi}, MatT{sE, DSi}, [&](int r, int c, float v) {
-      if (srfrn) v += sF[r];
-      const bool ok = c < n_here && !(exclude_pad && i0 + c == 0);
-      sS[r * SLD + c] = ok ? v : -INFINITY;
-    });
-    __syncthreads();
+                                                         Cand* __restrict__ ws, const int32_t* __restrict__ overflow) {
+  if (*overflow == 0) return;                      // the threshold scheme succeeded: nothing to do
+  TopkArgs a = {};
+  a.ly = ly; a.table = table; a.dense = dense; a.hidden = hidden; a.user_label = user_label;
+  a.B = B; a.L = L; a.exclude_pad = exclude_pad; a.k = k; a.n_chunks = n_chunks; a.user_splits = 1;
+  a.item_lo = item_lo; a.item_hi = item_hi;
+  topk_tiles(a, [&](int u0, int chunk, int64_t i0, lds_f* sS, int SLD) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int r = wave; r < 16; r += nw)
       if (u0 + r < B) {
         Cand* out = ws + ((int64_t)(u0 + r) * n_chunks + chunk) * k;
@@ -147,12 +276,13 @@ __global__ void __launch_bounds__(256) topk_stage1_kernel(srfrd_layout ly, const
           for (int q = 0; q < k; ++q)
             if (out[q].i >= 0) out[q].i += (int32_t)i0;       // chunk-local position -> item id
       }
-  }
+  });
 }
 
 __global__ void __launch_bounds__(256) topk_stage2_kernel(const Cand* __restrict__ ws, int B, int k, int n_chunks,
                                                          int64_t* __restrict__ topk_idx, float* __restrict__ topk_val,
-                                                         Cand* __restrict__ scratch_unused) {
+                                                         const int32_t* __restrict__ overflow) {
+  if (*overflow == 0) return;
   // one wave per user: k rounds of argmax over its n_chunks*k candidates (kept in global; -inf marks removed)
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -233,10 +363,19 @@ extern "C" int srfrd_predict_logits(const srfrd_layout* lay, const float* item_t
   return (int)hipGetLastError();
 }
 
+// workspace layout: [cmax B*nc f32][tau B f32][cursor B+1 i32 (+pad)][candidates B*kCandMax][fallback B*nc*k]
+static int64_t topk_off(int B, int k, int64_t nc, int which) {
+  int64_t off = 0;
+  const int64_t sizes[5] = {(int64_t)B * nc * 4, (int64_t)B * 4, ((int64_t)B + 4) * 4, (int64_t)B * kCandMax * (int64_t)sizeof(Cand),
+                            (int64_t)B * nc * k * (int64_t)sizeof(Cand)};
+  for (int i = 0; i < which; ++i) off += (sizes[i] + 255) & ~255ll;
+  return off;
+}
+
 extern "C" int64_t srfrd_topk_workspace_bytes(int B, int k, int64_t n_rows) {
   if (B <= 0 || k <= 0 || n_rows <= 0) return 0;
   const int64_t n_chunks = (n_rows + kChunk - 1) / kChunk;
-  return (int64_t)B * n_chunks * k * (int64_t)sizeof(Cand);
+  return topk_off(B, k, n_chunks, 5);
 }
 
 extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const float* item_table, const float* dense,
@@ -253,16 +392,37 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const float* item_tabl
   if (lds > (size_t)kLdsLimit) return SRFRD_E_UNSUPPORTED;
   static size_t s_attr = 0;
   if (lds > s_attr) {
-    if (hipFuncSetAttribute((const void*)topk_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)topk_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)topk_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)topk_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return SRFRD_E_DEVICE;
     s_attr = lds;
   }
-  hipLaunchKernelGGL(topk_stage1_kernel, dim3(n_chunks), dim3(256), lds, (hipStream_t)stream, *lay, item_table, dense,
-                     hidden, B, L, item_lo, item_hi, exclude_pad, user_label, k, n_chunks, (Cand*)workspace);
-  int rc = (int)hipGetLastError();
-  if (rc) return rc;
-  hipLaunchKernelGGL(topk_stage2_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const Cand*)workspace, B, k,
-                     n_chunks, topk_idx, topk_val, (Cand*)nullptr);
+  char* ws = (char*)workspace;
+  TopkArgs a = {};
+  a.ly = *lay; a.table = item_table; a.dense = dense; a.hidden = hidden; a.user_label = user_label;
+  a.B = B; a.L = L; a.exclude_pad = exclude_pad; a.k = k; a.n_chunks = n_chunks;
+  a.item_lo = item_lo; a.item_hi = item_hi;
+  a.cmax = (float*)(ws + topk_off(B, k, n_chunks, 0));
+  a.tau = (float*)(ws + topk_off(B, k, n_chunks, 1));
+  a.ccnt = (int32_t*)(ws + topk_off(B, k, n_chunks, 2));
+  a.cand = (Cand*)(ws + topk_off(B, k, n_chunks, 3));
+  Cand* fb = (Cand*)(ws + topk_off(B, k, n_chunks, 4));
+  const int user_tiles = (B + 15) / 16;
+  int splits = (2 * 256 + n_chunks - 1) / n_chunks;        // aim at >= 2 workgroups per CU
+  if (splits > user_tiles) splits = user_tiles;
+  if (splits < 1) splits = 1;
+  a.user_splits = splits;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(topk_max_kernel, dim3(n_chunks * splits), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(topk_tau_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(topk_collect_kernel, dim3(n_chunks * splits), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(topk_select_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a, topk_idx, topk_val);
+  // exhaustive path, armed only if a candidate list overflowed (device-side flag: no host synchronisation)
+  hipLaunchKernelGGL(topk_stage1_kernel, dim3(n_chunks), dim3(256), lds, st, *lay, item_table, dense, hidden, B, L, item_lo,
+                     item_hi, exclude_pad, user_label, k, n_chunks, fb, (const int32_t*)(a.ccnt + B));
+  hipLaunchKernelGGL(topk_stage2_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const Cand*)fb, B, k, n_chunks, topk_idx,
+                     topk_val, (const int32_t*)(a.ccnt + B));
   return (int)hipGetLastError();
 }
 

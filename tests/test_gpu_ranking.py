@@ -38,6 +38,22 @@ def test_topk_tie_break_prefers_lower_item_id():
     assert (idx.cpu() == torch.arange(1, 8)).all() and float((val - val[:, :1]).abs().max()) == 0.0
 
 
+def test_topk_mass_ties_take_the_exhaustive_fallback():
+    """more tied scores than a candidate list holds: the device-armed exhaustive path must still give the stable order."""
+    import srfrd_amd
+    m = srfrd_amd.SASRec(6000, 20, 50, 0.0, 1, 1, "cuda").cuda().eval()
+    with torch.no_grad():
+        m.item_emb.weight[1:] = m.item_emb.weight[1:2]
+        m.item_emb.weight[4000] = m.item_emb.weight[1] * 1.5          # one item that may outrank the tie
+    seq = torch.randint(1, 6000, (5, 20)).cuda()
+    idx, val = m.topk(None, seq, None, k=8)
+    with torch.no_grad():
+        h = m(None, seq, None)[0][:, -1]
+        ref = h @ m.item_emb.weight[1:].T
+    order = np.argsort(-ref.cpu().numpy(), axis=1, kind="stable")[:, :8] + 1
+    assert (idx.cpu().numpy() == order).all()
+
+
 def test_batched_evaluation_matches_oracle_metric():
     """HR@10 / NDCG@10 over 101 candidates per user (reference utils.py:576-598) for a golden model."""
     import srfrd_amd
