@@ -117,38 +117,10 @@ struct MatT {           // element (r, c) of the transpose of a row-major LDS ma
   int ld;
   __device__ __forceinline__ float operator()(int r, int c) const { return p[c * ld + r]; }
 };
-struct MatDrop {        // P with the attention-dropout multiplier applied on load (row = query, col = key)
-  const lds_f* p;
-  int ld;
-  DropSite ds;
-  __device__ __forceinline__ float operator()(int r, int c) const { return p[r * ld + c] * drop_mul(ds, r, c); }
-};
-struct MatDropT {       // transpose of the above: element (key, query)
-  const lds_f* p;
-  int ld;
-  DropSite ds;
-  __device__ __forceinline__ float operator()(int r, int c) const { return p[c * ld + r] * drop_mul(ds, c, r); }
-};
 struct MatOnes {        // [M | 1]: column `one_col` reads 1.0 - folds a column-sum (bias gradient) into a dW GEMM
   const lds_f* p;
   int ld, one_col;
   __device__ __forceinline__ float operator()(int r, int c) const { return c == one_col ? 1.0f : p[r * ld + c]; }
-};
-struct WgtNT {          // B(k, n) = W[n][k]  (y = x W^T, torch Linear / Conv1d(k=1) weight (N, K)); 0 outside
-  const float* w;
-  int N, K;
-  __device__ __forceinline__ float operator()(int k, int n) const {
-    const float v = w[min(n, N - 1) * K + min(k, K - 1)];     // clamped address + select: no branch in the MFMA loop
-    return (n < N && k < K) ? v : 0.0f;
-  }
-};
-struct WgtNN {          // B(k, n) = W[k][n]  (dx = dy W, weight (K, N)); 0 outside
-  const float* w;
-  int K, N;
-  __device__ __forceinline__ float operator()(int k, int n) const {
-    const float v = w[min(k, K - 1) * N + min(n, N - 1)];
-    return (k < K && n < N) ? v : 0.0f;
-  }
 };
 
 // Weights pre-swizzled into MFMA B-fragment order by srfrd_pack_weights: for strip nt and 16-deep k-chunk kc, lane l

@@ -31,6 +31,9 @@ __global__ void __launch_bounds__(NW * 64) mb(const float* packed, const float* 
     if (V == 6) { }
     if (V == 7) gemm_tiles<2>(NW, MT, NT, LP, Mat{S, SLD}, Mat{Bm, DS}, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; });
     if (V == 8) gemm_tiles<0>(NW, 1, NT, LP, OnesRow{}, Mat{A, DS}, [=](int r, int c, float v) { if (r == 0 && c < D) slab[blockIdx.x * 4096 + c] += v; });
+    if (V == 10) { if ((threadIdx.x >> 6) >= NW / 2) __builtin_amdgcn_s_sleep(8); gemm_packed(NW, MT, NT, DK, Mat{A, DS}, w, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; }); }
+    if (V == 11) { if ((threadIdx.x >> 6) >= NW / 2) __builtin_amdgcn_s_sleep(16); gemm_packed(NW, MT, NT, DK, Mat{A, DS}, w, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; }); }
+    if (V == 12) { for (int rep = 0; rep < 3; ++rep) gemm_packed(NW, MT, NT, DK, Mat{A, DS}, w, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v + (float)rep; }); }
     if (V == 9) gemm_packed(NW, MT, NT, DK, Mat{A, DS}, w, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = fmaxf(v * drop_mul(ds, r, c), 0.f); });
     __syncthreads();
   }
@@ -77,6 +80,9 @@ int main() {
     run<6>("empty phase (barrier only)", threads, packed, bias, slab, out);
     run<0>("gemm_packed, fragments preloaded", threads, packed, bias, slab, out);
     run<1>("gemm_packed + load_wfrag each phase", threads, packed, bias, slab, out);
+    run<10>("gemm_packed, waves >= nw/2 sleep(8)", threads, packed, bias, slab, out);
+    run<11>("gemm_packed, waves >= nw/2 sleep(16)", threads, packed, bias, slab, out);
+    run<12>("3 x gemm_packed in one phase", threads, packed, bias, slab, out);
     run<9>("gemm_packed + relu/dropout epilogue", threads, packed, bias, slab, out);
     run<2>("gemm_tiles<1> S = Q K^T", threads, packed, bias, slab, out);
     run<7>("gemm_tiles<2> O = P V", threads, packed, bias, slab, out);
