@@ -137,12 +137,12 @@ static int g_num_cu = 0;
   return g_num_cu;
 }
 
-// block size override for tuning runs (multiple of 64, <= 512)
+// block size override for tuning runs (multiple of 64, <= 1024)
 [[maybe_unused]] static int env_threads(const char* name, int dflt) {
   const char* e = getenv(name);
   if (!e) return dflt;
   const int v = atoi(e);
-  return (v >= 64 && v <= 512 && (v & 63) == 0) ? v : dflt;
+  return (v >= 64 && v <= 1024 && (v & 63) == 0) ? v : dflt;
 }
 
 [[maybe_unused]] static int fill_args(EncArgs& a, const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
