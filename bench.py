@@ -271,8 +271,9 @@ def time_kernels(tr, batches, steps):
     import ctypes as C
     from srfrd_amd import _lib
     from srfrd_amd._lib import check, ptr
-    names = ["srfrd_step_begin", "srfrd_encoder_fwd", "srfrd_encoder_bwd", "srfrd_reduce_dense", "srfrd_adam_step",
-             "srfrd_pack_weights", "srfrd_loss_finalize"]
+    names = ["srfrd_encoder_fwd", "srfrd_encoder_bwd", "srfrd_reduce_dense", "srfrd_adam_step", "srfrd_pack_weights"]
+    if tr.world > 1:
+        names.insert(4, "srfrd_loss_finalize")
     lib = _lib.lib()
     acc = {n: 0.0 for n in names}
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(steps)]

@@ -96,10 +96,13 @@ int srfrd_debug_shape(const srfrd_layout* lay, int L, int64_t* slot_floats, int3
  * Weight packing.  The fused kernels read every (out, in) weight matrix of the encoder (in_proj's three slices,
  * out_proj, conv1, conv2, last_conv) from `packed`: a copy pre-swizzled into v_mfma_f32_16x16x4_f32 B-fragment order
  * in both product forms (x W^T for the forward, dy W for the backward).  Call after every parameter update and before
- * srfrd_encoder_fwd / _bwd.  packed holds srfrd_packed_floats(lay) floats.
+ * srfrd_encoder_fwd / _bwd.  packed holds srfrd_packed_floats(lay) floats.  If `state` != NULL the same launch also
+ * performs srfrd_step_begin's advance for the NEXT step (the fused train step ends with this launch), else lr / betas
+ * are ignored.
  */
 int64_t srfrd_packed_floats(const srfrd_layout* lay);
-int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packed, void* stream);
+int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packed,
+                       uint32_t* state, double lr, double beta1, double beta2, void* stream);
 
 /*
  * Fused forward: embedding gather (+pos, +fake / user-label channel, pad mask), n_blocks x
@@ -153,9 +156,10 @@ int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const fl
                       float* dbg, int dbg_seq, void* stream);
 
 /* Sums the per-workgroup slabs into grad_dense (n_dense) in a fixed order (bitwise reproducible) and, if
- * loss_part != NULL, reduces it into stats[0..3] = {sum softplus(-pos), sum softplus(neg), count, 0}. */
+ * loss_part != NULL, reduces it into stats[0..3] = {sum softplus(-pos), sum softplus(neg), count, 0}; with loss_out != NULL
+ * (single rank: stats are already global) it also writes the loss, making srfrd_loss_finalize unnecessary. */
 int srfrd_reduce_dense(const float* grad_slabs, int n_slabs, int64_t n_dense, float* grad_dense,
-                       const float* loss_part, int B, float* stats, void* stream);
+                       const float* loss_part, int B, float* stats, float* loss_out, void* stream);
 
 /*
  * Optimizer state advance (one thread): t += 1, step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t)

@@ -42,12 +42,12 @@ SIGNATURES = {
     "srfrd_bwd_grid": (_i, [_i]),
     "srfrd_debug_shape": (_i, [_LP, _i, C.POINTER(_i64), C.POINTER(C.c_int32)]),
     "srfrd_packed_floats": (_i64, [_LP]),
-    "srfrd_pack_weights": (_i, [_LP, _P, _P, _P]),
+    "srfrd_pack_weights": (_i, [_LP, _P, _P, _P, _d, _d, _d, _P]),
     "srfrd_encoder_fwd": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
                                _P, _P, _P, _P, _P, _P, _P, _i64, _P, _i, _P]),
     "srfrd_encoder_bwd": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
                                _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, _i64, _P, _i, _P]),
-    "srfrd_reduce_dense": (_i, [_P, _i, _i64, _P, _P, _i, _P, _P]),
+    "srfrd_reduce_dense": (_i, [_P, _i, _i64, _P, _P, _i, _P, _P, _P]),
     "srfrd_step_begin": (_i, [_P, _d, _d, _d, _P]),
     "srfrd_adam_step": (_i, [_P, _P, _P, _P, _i64, _i64, _i64, _i64, _d, _d, _d, _P, _P, _P]),
     "srfrd_loss_finalize": (_i, [_P, _P, _P]),

@@ -645,6 +645,18 @@ __device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f
   }
 }
 
+// optimizer state advance (one thread): t += 1, Adam bias corrections in double precision as torch computes them on
+// the host, dropout seed of the step.  state: uint32[8] {t, base_seed, step_seed, -, f32 step_size, f32 bc2_sqrt, -, -}
+__device__ __forceinline__ void step_advance(uint32_t* state, double lr, double b1, double b2) {
+  const uint32_t t = state[0] + 1u;
+  state[0] = t;
+  state[2] = step_seed(state[1], t);
+  const double bc1 = 1.0 - pow(b1, (double)t);
+  const double bc2 = 1.0 - pow(b2, (double)t);
+  ((float*)state)[4] = (float)(lr / bc1);
+  ((float*)state)[5] = (float)sqrt(bc2);
+}
+
 __device__ __forceinline__ float softplus_f(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
 __device__ __forceinline__ float sigmoid_f(float z) { return 1.0f / (1.0f + expf(-z)); }
 

@@ -16,7 +16,10 @@ namespace srfrd {
 // weight packing: canonical (N, K) row-major weights -> MFMA B-fragment order, both product forms
 // ================================================================================================
 __global__ void __launch_bounds__(256) pack_weights_kernel(const srfrd_layout ly, const float* __restrict__ dense,
-                                                          float* __restrict__ packed) {
+                                                          float* __restrict__ packed, uint32_t* state, double lr, double b1,
+                                                          double b2) {
+  // the last launch of a fused train step also advances the optimizer state for the NEXT step (saves a launch)
+  if (state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) step_advance(state, lr, b1, b2);
   const int mf = blockIdx.x, mat = mf >> 1, form = mf & 1;
   const int nb6 = ly.n_blocks * 6;
   const float* W;
@@ -73,11 +76,12 @@ extern "C" int64_t srfrd_packed_floats(const srfrd_layout* lay) {
   return (int64_t)(lay->n_blocks * 6 + 1) * 2 * kPackFloats;
 }
 
-extern "C" int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packed, void* stream) {
+extern "C" int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packed, uint32_t* state, double lr,
+                                  double beta1, double beta2, void* stream) {
   if (!lay || !dense || !packed) return SRFRD_E_ARG;
   if (lay->D > SRFRD_MAX_D) return SRFRD_E_UNSUPPORTED;
   hipLaunchKernelGGL(pack_weights_kernel, dim3((lay->n_blocks * 6 + 1) * 2), dim3(256), 0, (hipStream_t)stream, *lay, dense,
-                     packed);
+                     packed, state, lr, beta1, beta2);
   return (int)hipGetLastError();
 }
 

@@ -9,7 +9,7 @@ namespace srfrd {
 // result is bitwise reproducible.  Block 0 also reduces the BCE partials.
 __global__ void __launch_bounds__(256) reduce_dense_kernel(const float* __restrict__ slabs, int n_slabs, int64_t n_dense,
                                                           float* __restrict__ grad_dense, const float* __restrict__ loss_part,
-                                                          int B, float* __restrict__ stats) {
+                                                          int B, float* __restrict__ stats, float* __restrict__ loss_out) {
   __shared__ float part[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -42,21 +42,18 @@ __global__ void __launch_bounds__(256) reduce_dense_kernel(const float* __restri
       float s = 0.f;
       for (int w = 0; w < 4; ++w) s += red[w][threadIdx.x];
       stats[threadIdx.x] = s;
+      red[0][threadIdx.x] = s;
     }
     if (threadIdx.x == 3) stats[3] = 0.f;
+    if (loss_out != nullptr) {               // single-rank fast path: the loss of reference trainer.py:36-38 right here
+      __syncthreads();
+      if (threadIdx.x == 0) loss_out[0] = red[0][0] / red[0][2] + red[0][1] / red[0][2];
+    }
   }
 }
 
 __global__ void step_begin_kernel(uint32_t* state, double lr, double b1, double b2) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const uint32_t t = state[0] + 1u;
-    state[0] = t;
-    state[2] = step_seed(state[1], t);
-    const double bc1 = 1.0 - pow(b1, (double)t);
-    const double bc2 = 1.0 - pow(b2, (double)t);
-    ((float*)state)[4] = (float)(lr / bc1);
-    ((float*)state)[5] = (float)sqrt(bc2);
-  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) step_advance(state, lr, b1, b2);
 }
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float b1, float b2, float eps,
@@ -112,12 +109,12 @@ __global__ void loss_finalize_kernel(const float* stats, float* loss_out) {
 using namespace srfrd;
 
 extern "C" int srfrd_reduce_dense(const float* grad_slabs, int n_slabs, int64_t n_dense, float* grad_dense,
-                                  const float* loss_part, int B, float* stats, void* stream) {
+                                  const float* loss_part, int B, float* stats, float* loss_out, void* stream) {
   if (!grad_slabs || !grad_dense || n_slabs <= 0 || n_dense <= 0) return SRFRD_E_ARG;
   if ((loss_part != nullptr) != (stats != nullptr)) return SRFRD_E_ARG;
   const int grid = (int)((n_dense + 63) / 64);
   hipLaunchKernelGGL(reduce_dense_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_slabs, n_slabs, n_dense,
-                     grad_dense, loss_part, B, stats);
+                     grad_dense, loss_part, B, stats, loss_part ? loss_out : nullptr);
   return (int)hipGetLastError();
 }
 

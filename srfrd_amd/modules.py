@@ -206,7 +206,7 @@ class _SRFRDBase(nn.Module):
         if self._packed is None or self._packed.device != flat.device:
             self._packed = torch.empty(_lib.lib().srfrd_packed_floats(C.byref(lay)), device=flat.device, dtype=torch.float32)
         check(_lib.lib().srfrd_pack_weights(C.byref(lay), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad),
-                                            ptr(self._packed), _stream()), "srfrd_pack_weights")
+                                            ptr(self._packed), None, 0.0, 0.0, 0.0, _stream()), "srfrd_pack_weights")
         return self._packed
 
     def _scratch_for(self, B, L, backward):
@@ -253,7 +253,8 @@ class _SRFRDBase(nn.Module):
             ptr(out["save_h1"]), ptr(d_hidden), ptr(d_pl), ptr(d_nl), 0, ptr(gflat), ptr(slabs), ptr(scratch), n_scr,
             ptr(dbg), int(dbg_seq), _stream()), "srfrd_encoder_bwd")
         check(_lib.lib().srfrd_reduce_dense(ptr(slabs), n_slabs, lay.n_dense,
-                                            C.c_void_p(gflat.data_ptr() + 4 * self.n_table_pad), None, B, None, _stream()),
+                                            C.c_void_p(gflat.data_ptr() + 4 * self.n_table_pad), None, B, None, None,
+                                            _stream()),
               "srfrd_reduce_dense")
         return gflat
 

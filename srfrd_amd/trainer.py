@@ -2,8 +2,8 @@
 
     forward -> masked BCE(pos, 1) + BCE(neg, 0) over pos != 0 -> backward -> Adam(lr, betas=(0.9, 0.98))
 
-as seven stream-ordered launches on persistent buffers (step_begin, encoder_fwd, encoder_bwd, reduce_dense, adam_step,
-pack_weights, loss_finalize), captured into one HIP graph when no collective sits in the middle.  Differences from the reference
+as five stream-ordered launches on persistent buffers (encoder_fwd, encoder_bwd, reduce_dense [+ loss], adam_step,
+pack_weights [+ optimizer-state advance for the next step]), captured into one HIP graph when no collective sits in the middle.  Differences from the reference
 loop, all behaviour-preserving: the loss is never synchronised to the host (``loss`` stays a device scalar), the
 ``l2_emb * ||theta||`` term (trainer.py:39) is supported only at its default 0.0 where it contributes exactly nothing,
 and dropout masks come from the coordinate hash of csrc/srfrd_rng.h instead of torch's Bernoulli stream.
@@ -79,6 +79,8 @@ class FusedTrainer:
         self.loss_part = torch.empty(B, 3, **f32)
         self.loss = torch.zeros(1, **f32)
         self.packed = model.pack_weights()
+        check(_lib.lib().srfrd_step_begin(ptr(self.state), self.lr, self.betas[0], self.betas[1],
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "srfrd_step_begin")
         self.use_graph = bool(use_graph)
         self._graph_a = self._graph_b = None
         self.steps_done = 0
@@ -98,7 +100,6 @@ class FusedTrainer:
         p = self.model.dropout_rate if self.model.training else 0.0
         seed_dev = C.c_void_p(self.state.data_ptr() + 8)
         seq0 = self.rank * self.B
-        check(L_.srfrd_step_begin(ptr(self.state), self.lr, self.betas[0], self.betas[1], st), "srfrd_step_begin")
         check(L_.srfrd_encoder_fwd(C.byref(lay), ptr(self.flat), self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
                                    ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
                                    ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.loss_part),
@@ -108,9 +109,10 @@ class FusedTrainer:
                                    ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), None, None, None, 1,
                                    ptr(self.grad), ptr(self.slabs), ptr(self.scratch), self.n_scratch, None, 0, st),
               "srfrd_encoder_bwd")
+        # single rank: the reduction also finalises the loss; with DP the loss needs the all-reduced stats first
         check(L_.srfrd_reduce_dense(ptr(self.slabs), self.n_slabs, lay.n_dense, self._dense_ptr(self.grad),
-                                    ptr(self.loss_part), self.B, C.c_void_p(self.grad.data_ptr() + 4 * self.n_flat), st),
-              "srfrd_reduce_dense")
+                                    ptr(self.loss_part), self.B, C.c_void_p(self.grad.data_ptr() + 4 * self.n_flat),
+                                    ptr(self.loss) if self.world == 1 else None, st), "srfrd_reduce_dense")
 
     def _enqueue_update(self):
         L_, st = _lib.lib(), self._stream()
@@ -118,8 +120,12 @@ class FusedTrainer:
         check(L_.srfrd_adam_step(ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v), self.n_flat, 0, self.n_flat,
                                  self.n_tab, self.betas[0], self.betas[1], self.eps, ptr(self.state), stats, st),
               "srfrd_adam_step")
-        check(L_.srfrd_pack_weights(C.byref(self.lay), self._dense_ptr(self.flat), ptr(self.packed), st), "srfrd_pack_weights")
-        check(L_.srfrd_loss_finalize(stats, ptr(self.loss), st), "srfrd_loss_finalize")
+        if self.world > 1:
+            check(L_.srfrd_loss_finalize(stats, ptr(self.loss), st), "srfrd_loss_finalize")
+        # re-pack the stepped weights; the same launch advances the optimizer state (t, bias corrections, seed) for the
+        # next step
+        check(L_.srfrd_pack_weights(C.byref(self.lay), self._dense_ptr(self.flat), ptr(self.packed), ptr(self.state),
+                                    self.lr, self.betas[0], self.betas[1], st), "srfrd_pack_weights")
 
     def _capture(self):
         # warm-up on a side stream (sets the LDS attributes, loads code objects), then capture
