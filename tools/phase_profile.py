@@ -21,15 +21,16 @@ def build():
     tmp = "/tmp/srfrd_stamps"
     os.makedirs(tmp + "/srfrd_amd/csrc", exist_ok=True)
     os.makedirs(tmp + "/include", exist_ok=True)
-    for which, fname in (("fwd", "srfrd_encoder_fwd.hip"), ("bwd", "srfrd_encoder_bwd.hip")):
+    for f in os.listdir(CSRC):
+        open(f"{tmp}/srfrd_amd/csrc/{f}", "w").write(open(os.path.join(CSRC, f)).read())
+    for which in ("fwd", "bwd"):
+        fname = f"srfrd_encoder_{which}_kernel.inc"
         out = _stamp_file(os.path.join(CSRC, fname), which, labels)
         open(f"{tmp}/srfrd_amd/csrc/{fname}", "w").write("\n".join(out))
-    for f in ("srfrd_dev.h", "srfrd_rng.h", "srfrd_enc_common.h", "srfrd_optim.hip", "srfrd_rank.hip"):
-        open(f"{tmp}/srfrd_amd/csrc/{f}", "w").write(open(os.path.join(CSRC, f)).read())
     open(f"{tmp}/include/srfrd_hip.h", "w").write(open(os.path.join(ROOT, "include", "srfrd_hip.h")).read())
+    srcs = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
-           "-DSRFRD_STAMPS", "-o", OUT] + [f"{tmp}/srfrd_amd/csrc/{f}" for f in
-                                           ("srfrd_encoder_fwd.hip", "srfrd_encoder_bwd.hip", "srfrd_optim.hip", "srfrd_rank.hip")]
+           "-DSRFRD_STAMPS", "-o", OUT] + [f"{tmp}/srfrd_amd/csrc/{f}" for f in srcs]
     subprocess.run(cmd, check=True)
     import json
     json.dump({f"{k[0]}:{k[1]}": v for k, v in labels.items()}, open(OUT + ".labels.json", "w"), indent=0)
