@@ -248,7 +248,10 @@ __device__ __forceinline__ WaveTiles wave_tiles(int nw, int m_tiles, int n_tiles
   t.active = wave < n_tiles * t.mgroups;
   t.nt = wave % n_tiles;
   t.g = wave / n_tiles;
-  t.n = t.active && t.g < m_tiles ? (m_tiles - t.g + t.mgroups - 1) / t.mgroups : 0;
+  // (when the row tiles divide evenly - every specialised shape - the count is a constant and the G = 1 / 3 code
+  // paths of the callers fold away)
+  if (m_tiles % t.mgroups == 0) t.n = t.active ? m_tiles / t.mgroups : 0;
+  else t.n = t.active && t.g < m_tiles ? (m_tiles - t.g + t.mgroups - 1) / t.mgroups : 0;
   return t;
 }
 
@@ -266,20 +269,33 @@ __device__ __forceinline__ SlabPre slab_preload(int nw, int m_tiles, int n_tiles
   return p;
 }
 
+// Makes the wave wait for a preload HERE.  vmcnt retires in order and counts stores too, so a first use that sits
+// behind another dW GEMM's slab stores would wait for their acknowledgement; calling this before the first store of
+// a phase keeps the stores of the phase fire-and-forget.
+__device__ __forceinline__ void slab_ready(SlabPre& p) {
+#pragma unroll
+  for (int j = 0; j < kMW; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(p.v[j][e]));
+}
+
 // dW group: C-in from `pre` (tiles J0 .. J0+G-1 of this wave), full k range, plain store of C-in + acc
 template <int G, int J0, class AL, class BL>
 __device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int k_end, const AL& a, const BL& b,
                                                 const SlabWB& sl, const SlabPre& pre, int li, int lq) {
+  // The old slab values ARE the accumulators' initial value: the one wait for their loads sits before the first MFMA
+  // and the stores below depend on nothing in flight (an add after the loop made every store wait for vmcnt(0), i.e.
+  // for the acknowledgement of the store before it - eight serial L2 round trips per wave and GEMM).
   f32x4 acc[G];
 #pragma unroll
-  for (int j = 0; j < G; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < G; ++j) acc[j] = f32x4{pre.v[J0 + j][0], pre.v[J0 + j][1], pre.v[J0 + j][2], pre.v[J0 + j][3]};
   mma_group<G>(acc, a, b, (mt << 4) + li, mgroups << 4, n0 + li, 0, k_end, lq);
 #pragma unroll
   for (int j = 0; j < G; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float* ptr = sl.ptr(((mt + j * mgroups) << 4) + (lq << 2) + e, n0 + li);
-      if (ptr != nullptr) *ptr = pre.v[J0 + j][e] + acc[j][e];
+      if (ptr != nullptr) *ptr = acc[j][e];
     }
 }
 

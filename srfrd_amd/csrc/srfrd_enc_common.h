@@ -65,6 +65,57 @@ __device__ __forceinline__ void launder(float*& p) {
 #define STAMP(id) do {} while (0)
 #endif
 
+// A contiguous [rows][cols] fp32 block of global memory on its way into an LDS matrix [rows][ld].  load() puts every
+// element the thread owns in flight at once: indices past the end are clamped instead of predicated, so the loads are
+// unconditional, stay back to back, and the block costs ONE memory round trip (a `for (i = tid; ...) lds[..] = g[i]`
+// loop that the compiler does not unroll pays one round trip - 1.5 to 2 k cycles from L2 / HBM here - per iteration).
+// store() writes them to LDS; a caller may put independent work between the two.  V2: 8-byte accesses (cols even and
+// the block 8-byte aligned).  One G2L covers ITER * blockDim elements (pairs); copy_g2l walks larger blocks in chunks.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef SRFRD_BUF_GLOBAL
+typedef f32x2 lds_f2;
+#else
+typedef __attribute__((address_space(3))) f32x2 lds_f2;
+#endif
+template <int ITER, bool V2>
+struct G2L {
+  float v[ITER][V2 ? 2 : 1];
+  __device__ __forceinline__ void load(const float* src, int rows, int cols, int nthr, int base = 0) {
+    const int n = V2 ? rows * (cols >> 1) : rows * cols;
+#pragma unroll
+    for (int u = 0; u < ITER; ++u) {
+      const int i = min(base + u * nthr + (int)threadIdx.x, n - 1);
+      if constexpr (V2) {
+        const f32x2 t = reinterpret_cast<const f32x2*>(src)[i];
+        v[u][0] = t.x; v[u][1] = t.y;
+      } else {
+        v[u][0] = src[i];
+      }
+    }
+  }
+  __device__ __forceinline__ void store(lds_f* dst, int ld, int rows, int cols, int nthr, int base = 0) const {
+    const int cw = V2 ? cols >> 1 : cols, n = rows * cw;
+#pragma unroll
+    for (int u = 0; u < ITER; ++u) {
+      const int i = base + u * nthr + (int)threadIdx.x;
+      if (i < n) {
+        const int t = i / cw, c = i - t * cw;
+        if constexpr (V2) *reinterpret_cast<lds_f2*>(dst + t * ld + 2 * c) = f32x2{v[u][0], v[u][1]};
+        else dst[t * ld + c] = v[u][0];
+      }
+    }
+  }
+};
+template <int ITER, bool V2>
+__device__ __forceinline__ void copy_g2l(lds_f* dst, int ld, const float* src, int rows, int cols, int nthr) {
+  const int n = V2 ? rows * (cols >> 1) : rows * cols;
+  for (int base = 0; base < n; base += ITER * nthr) {
+    G2L<ITER, V2> g;
+    g.load(src, rows, cols, nthr, base);
+    g.store(dst, ld, rows, cols, nthr, base);
+  }
+}
+
 // LayerNorm weights / biases -> LDS once per workgroup (read by every row pass of every sequence)
 __device__ __forceinline__ void fill_ln_cache(lds_f* s_ln, const float* P, const Dims& ly) {
   const int D = ly.D;

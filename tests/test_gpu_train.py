@@ -130,7 +130,8 @@ def test_dropout_statistics_and_backward_consistency():
 
 
 @pytest.mark.parametrize("kind,d_item,d_fake,L", [("SASRec", 64, 0, 20), ("SRFR", 43, 5, 33), ("SRFRN", 50, 10, 17),
-                                                  ("SRFU_R", 32, 0, 48), ("SASRec", 16, 0, 5)])
+                                                  ("SRFU_R", 32, 0, 48), ("SASRec", 16, 0, 5), ("SASRec", 48, 0, 64),
+                                                  ("SRFRN", 54, 10, 60)])
 def test_other_widths_and_lengths_match_oracle(kind, d_item, d_fake, L):
     """Generic (run-time geometry) kernels: widths that are / are not multiples of 16 (bias-gradient folding on and off),
     the reference constructors' default 50 + 10, odd lengths; forward, loss and every gradient vs the oracle."""
@@ -150,6 +151,29 @@ def test_other_widths_and_lengths_match_oracle(kind, d_item, d_fake, L):
     seq, rsq, pos, prs, neg, nrs = cuda(*batch)
     h, pl, nl = model(None, seq, rsq, pos, prs, neg, nrs)
     assert maxerr(h, h_o) < TOL and maxerr(pl, pl_o) < TOL and maxerr(nl, nl_o) < TOL
+    loss = _loss(pl, nl, pos)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_o)) < TOL
+    for k, p in model.named_parameters():
+        assert maxerr(p.grad, grads_o[k]) < TOL, k
+
+
+@pytest.mark.parametrize("kind", ["SASRec", "SRFRN"])
+def test_generic_kernels_on_the_specialised_shape(kind, monkeypatch):
+    """SRFRD_GENERIC=1 routes hidden-50 shapes through the run-time-geometry instantiation: same gradients as the
+    oracle at the bench geometry (L = 50: an [L][D] block is larger than one copy chunk of the generic kernel)."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, maxerr, random_sd
+    monkeypatch.setenv("SRFRD_GENERIC", "1")
+    I, B, L = 300, 9, 50
+    cfg = O.Cfg(kind, I, L, 50) if kind == "SASRec" else O.Cfg(kind, I, L, 45, d_fake=5)
+    sd = random_sd(cfg, 4)
+    model = build_model(cfg, sd).train()
+    batch = srfrd_amd.synthetic_batch(I, L, B, seed=2, device="cpu", min_len=1)[1:]
+    loss_o, grads_o, h_o, pl_o, nl_o = O.grads_of(cfg, sd, batch)
+    seq, rsq, pos, prs, neg, nrs = cuda(*batch)
+    h, pl, nl = model(None, seq, rsq, pos, prs, neg, nrs)
+    assert maxerr(h, h_o) < TOL
     loss = _loss(pl, nl, pos)
     loss.backward()
     assert abs(float(loss.detach()) - float(loss_o)) < TOL
