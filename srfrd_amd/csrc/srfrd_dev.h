@@ -134,20 +134,12 @@ struct PackedB {
   __device__ __forceinline__ float4 chunk(int nt, int kc, int lane) const { return p[(nt * kPackKC + kc) * 64 + lane]; }
 };
 
-// dW epilogue: read-modify-write of a (R x C) weight-gradient block (+ the bias gradient in column C, fed by the
-// ones column of MatOnes) in this workgroup's slab.  The old values are requested BEFORE the MFMA chain so their
-// latency hides under it; `rmw == 0` (first sequence of the workgroup: the slab is still zero) skips the loads.
+// dW epilogue target: a (R x C) weight-gradient block (+ the bias gradient in column C, fed by the ones column of
+// MatOnes) in this workgroup's slab; `rmw == 0` for the first sequence of the workgroup (store), 1 afterwards (add).
 struct SlabWB {
   float* w;
   float* b;      // may be null
   int R, C, rmw;
-  __device__ __forceinline__ float* ptr(int r, int c) const {
-    if (r < R) {
-      if (c < C) return w + r * C + c;
-      if (c == C && b != nullptr) return b + r;
-    }
-    return nullptr;
-  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -231,12 +223,6 @@ __device__ __forceinline__ void gemm_group(int mt, int mgroups, int n0, int k_en
 
 constexpr int kMW = 4;     // row tiles a wave accumulates at once
 
-// Old slab values of the (<= kMW) row tiles a wave owns in a dW GEMM, requested ahead of time (slab_preload) so the
-// L2 / Infinity-Cache latency of the read-modify-write hides under whatever the workgroup does in between.
-struct SlabPre {
-  float v[kMW][4];
-};
-
 // tiles of this wave in a (m_tiles x n_tiles) GEMM with m_tiles <= kMW * mgroups: unit, strip, first tile, count
 struct WaveTiles {
   int active, nt, g, mgroups, n;
@@ -255,67 +241,49 @@ __device__ __forceinline__ WaveTiles wave_tiles(int nw, int m_tiles, int n_tiles
   return t;
 }
 
-__device__ __forceinline__ SlabPre slab_preload(int nw, int m_tiles, int n_tiles, const SlabWB& sl) {
-  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
-  const WaveTiles t = wave_tiles(nw, m_tiles, n_tiles);
-  SlabPre p;
-#pragma unroll
-  for (int j = 0; j < kMW; ++j)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float* ptr = (j < t.n) ? sl.ptr(((t.g + j * t.mgroups) << 4) + (lq << 2) + e, (t.nt << 4) + li) : nullptr;
-      p.v[j][e] = (sl.rmw && ptr != nullptr) ? *ptr : 0.f;
-    }
-  return p;
-}
-
-// Makes the wave wait for a preload HERE.  vmcnt retires in order and counts stores too, so a first use that sits
-// behind another dW GEMM's slab stores would wait for their acknowledgement; calling this before the first store of
-// a phase keeps the stores of the phase fire-and-forget.
-__device__ __forceinline__ void slab_ready(SlabPre& p) {
-#pragma unroll
-  for (int j = 0; j < kMW; ++j)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(p.v[j][e]));
-}
-
-// dW group: C-in from `pre` (tiles J0 .. J0+G-1 of this wave), full k range, plain store of C-in + acc
-template <int G, int J0, class AL, class BL>
+// dW group.  The first sequence of a workgroup stores its tiles (the slab needs no zero-fill); every later one adds
+// with no-return float atomics, executed at L2: no old value travels to the CU, so nothing in the wave ever waits on
+// the slab (a load + add + store made each store wait, through the in-order vmcnt, for the one before it).  The slab
+// is private to the workgroup and a given element is always added by the same lane, in sequence order: deterministic.
+template <int G, class AL, class BL>
 __device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int k_end, const AL& a, const BL& b,
-                                                const SlabWB& sl, const SlabPre& pre, int li, int lq) {
-  // The old slab values ARE the accumulators' initial value: the one wait for their loads sits before the first MFMA
-  // and the stores below depend on nothing in flight (an add after the loop made every store wait for vmcnt(0), i.e.
-  // for the acknowledgement of the store before it - eight serial L2 round trips per wave and GEMM).
+                                                const SlabWB& sl, int li, int lq) {
   f32x4 acc[G];
 #pragma unroll
-  for (int j = 0; j < G; ++j) acc[j] = f32x4{pre.v[J0 + j][0], pre.v[J0 + j][1], pre.v[J0 + j][2], pre.v[J0 + j][3]};
+  for (int j = 0; j < G; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   mma_group<G>(acc, a, b, (mt << 4) + li, mgroups << 4, n0 + li, 0, k_end, lq);
+  // element (r, c): r < R rows of the weight gradient; column C is the bias gradient (ones column of the B operand)
+  const int c = n0 + li;
+  const bool in_w = c < sl.C, in_b = c == sl.C && sl.b != nullptr;
+  float* colbase = in_w ? sl.w + c : sl.b;
+  const int rstride = in_w ? sl.C : 1;
+  if (in_w || in_b) {
 #pragma unroll
-  for (int j = 0; j < G; ++j)
+    for (int j = 0; j < G; ++j)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float* ptr = sl.ptr(((mt + j * mgroups) << 4) + (lq << 2) + e, n0 + li);
-      if (ptr != nullptr) *ptr = acc[j][e];
-    }
+      for (int e = 0; e < 4; ++e) {
+        const int r = ((mt + j * mgroups) << 4) + (lq << 2) + e;
+        if (r < sl.R) {
+          float* ptr = colbase + r * rstride;
+          if (sl.rmw) atomicAdd(ptr, acc[j][e]);
+          else *ptr = acc[j][e];
+        }
+      }
+  }
 }
 
 // m_tiles <= kMW * mgroups and n_tiles <= number of waves (true for every weight-gradient GEMM: <= 4 x 4 tiles)
 template <class AL, class BL>
-__device__ __forceinline__ void gemm_slab(int nw, int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl, const SlabPre& pre) {
+__device__ __forceinline__ void gemm_slab(int nw, int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl) {
   const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
   const WaveTiles t = wave_tiles(nw, m_tiles, n_tiles);
   const int n0 = t.nt << 4;
-  if (t.n >= 4) gemm_group_slab<4, 0>(t.g, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
+  if (t.n >= 4) gemm_group_slab<4>(t.g, t.mgroups, n0, k_end, a, b, sl, li, lq);
   else {
-    if (t.n >= 2) gemm_group_slab<2, 0>(t.g, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
-    if (t.n == 3) gemm_group_slab<1, 2>(t.g + 2 * t.mgroups, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
-    if (t.n == 1) gemm_group_slab<1, 0>(t.g, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
+    if (t.n >= 2) gemm_group_slab<2>(t.g, t.mgroups, n0, k_end, a, b, sl, li, lq);
+    if (t.n == 3) gemm_group_slab<1>(t.g + 2 * t.mgroups, t.mgroups, n0, k_end, a, b, sl, li, lq);
+    if (t.n == 1) gemm_group_slab<1>(t.g, t.mgroups, n0, k_end, a, b, sl, li, lq);
   }
-}
-template <class AL, class BL>
-__device__ __forceinline__ void gemm_slab(int nw, int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl) {
-  const SlabPre pre = slab_preload(nw, m_tiles, n_tiles, sl);
-  gemm_slab(nw, m_tiles, n_tiles, k_end, a, b, sl, pre);
 }
 
 // Weight fragments of the strip this wave owns in a packed GEMM, requested ahead of use (one phase early where the

@@ -56,13 +56,20 @@ __device__ __forceinline__ void launder(float*& p) {
 // workgroup barrier): thread 0 adds the s_memtime delta of each phase into a per-workgroup table that aliases the
 // debug-tap buffer.  The shipped library contains no stamp.
 #ifdef SRFRD_STAMPS
-#define STAMP_INIT unsigned long long* stamp_acc = (unsigned long long*)a.dbg + (int64_t)blockIdx.x * 128; \
+// (accumulated in LDS and flushed once: a global read-modify-write per stamp would put a memory round trip of its own
+// into every phase it measures)
+#define STAMP_INIT __shared__ unsigned long long stamp_lds[128]; \
+                   if (threadIdx.x < 128) stamp_lds[threadIdx.x] = 0; \
+                   __syncthreads(); \
                    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
-#define STAMP(id) do { if (threadIdx.x == 0 && a.dbg) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-                       stamp_acc[id] += t_ - stamp_prev; stamp_prev = t_; } } while (0)
+#define STAMP(id) do { if (threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                       stamp_lds[id] += t_ - stamp_prev; stamp_prev = t_; } } while (0)
+#define STAMP_FLUSH do { __syncthreads(); if (threadIdx.x < 128 && a.dbg) \
+                       ((unsigned long long*)a.dbg)[(int64_t)blockIdx.x * 128 + threadIdx.x] = stamp_lds[threadIdx.x]; } while (0)
 #else
 #define STAMP_INIT
 #define STAMP(id) do {} while (0)
+#define STAMP_FLUSH do {} while (0)
 #endif
 
 // A contiguous [rows][cols] fp32 block of global memory on its way into an LDS matrix [rows][ld].  load() puts every

@@ -41,6 +41,8 @@ def _stamp_file(path, which, labels):
     lines = src.split("\n")
     out, n, kernel = [], 0, None
     for ln, line in enumerate(lines):
+        if line == "}" and kernel:
+            out.append("  STAMP_FLUSH;")
         out.append(line)
         if "encoder_%s_kernel(const EncArgs a) {" % which in line:
             kernel, n = which, 0
@@ -85,11 +87,23 @@ def run():
     ids = m._prep(seq, None, pos, None, neg, None)
     for which in ("fwd", "bwd"):
         dbg = torch.zeros(1024, 128, device="cuda", dtype=torch.int64)
+        dbg2 = torch.zeros(1024, 128, device="cuda", dtype=torch.int64)
         out = m._launch_fwd(*ids, 0.5, 7, save=True, dbg=dbg.view(torch.float32) if which == "fwd" else None)
         if which == "bwd":
             dpl = torch.full_like(out["pos_logits"], 0.1)
             m._launch_bwd(*ids, 0.5, 7, out, None, dpl, dpl, dbg=dbg.view(torch.float32))
         torch.cuda.synchronize()
+        # duration of the stamped kernels themselves (events), to calibrate ticks -> time
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            if which == "fwd":
+                m._launch_fwd(*ids, 0.5, 7, save=True, dbg=dbg2.view(torch.float32))
+            else:
+                m._launch_bwd(*ids, 0.5, 7, out, None, dpl, dpl, dbg=dbg2.view(torch.float32))
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"   stamped {which} kernel: {e0.elapsed_time(e1) / 5 * 1000:.1f} us per launch")
         d = dbg.cpu().double()
         used = d[d.sum(1) > 0]
         mean = used.mean(0)
