@@ -86,6 +86,11 @@ int srfrd_lds_bytes(const srfrd_layout* lay, int L, int64_t* fwd_bytes, int64_t*
  * workgroup) - every shape runs on the GPU, the LDS-resident shapes run faster. */
 int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64_t* fwd_floats, int64_t* bwd_floats);
 
+/* [host] floats of the forward's `save_aux` checkpoint buffer for (B, L): per block and sequence the FFN hidden
+ * activation relu(drop(.)) (L, D), the attention output P v (L, D) and the attention probabilities (L, LP = L rounded
+ * up to 16), the latter sign-coded with the attention-dropout mask (a dropped entry is stored negated). */
+int64_t srfrd_aux_floats(const srfrd_layout* lay, int B, int L);
+
 /* [host] number of persistent workgroups the backward launches for batch B (= rows of `grad_slabs`). */
 int srfrd_bwd_grid(int B);
 
@@ -118,7 +123,7 @@ int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packe
  *    (seed, site, seq_index0 + b, row, col); if seed_dev != NULL the seed is read from device memory
  *  hidden (B,L,d_out), pos_logits/neg_logits (B,L) outputs (logit pointers may be NULL iff the id pointer is)
  *  save_x (n_blocks+1, B, L, D): block inputs and the last block's output; save_h1 (n_blocks, B, L, D):
- *    post-attention residual; both NULL for inference
+ *    post-attention residual; save_aux: srfrd_aux_floats() floats (see there); all three NULL for inference
  *  loss_part (B,3) or NULL: per sequence {sum softplus(-pos), sum softplus(neg), count} over pos_ids != 0
  *  scratch / scratch_floats: srfrd_scratch_floats() floats of workspace (NULL / 0 when that is 0)
  *  dbg / dbg_seq: debug taps of one sequence (tests only; NULL otherwise)
@@ -129,12 +134,14 @@ int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const fl
                       const int64_t* neg_ids, const int64_t* neg_fake,
                       int B, int L, double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
                       float* hidden, float* pos_logits, float* neg_logits,
-                      float* save_x, float* save_h1, float* loss_part,
+                      float* save_x, float* save_h1, float* save_aux, float* loss_part,
                       float* scratch, int64_t scratch_floats,
                       float* dbg, int dbg_seq, void* stream);
 
 /*
- * Fused backward of the above (recomputes block internals in LDS from save_x / save_h1).  Replaces the
+ * Fused backward of the above: LayerNorms and the q / k / v projections are recomputed in LDS from save_x / save_h1;
+ * the FFN hidden activation, the attention probabilities (with their dropout mask) and the attention output are read
+ * back from save_aux.  Replaces the
  * autograd pass behind `loss.backward()` (reference trainer.py:40).
  *
  *  fused_bce != 0: d(pos_logits) = (sigmoid(pos)-1)[pos_ids!=0], d(neg_logits) = sigmoid(neg)[pos_ids!=0]
@@ -149,7 +156,7 @@ int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const fl
                       const int64_t* neg_ids, const int64_t* neg_fake,
                       int B, int L, double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
                       const float* hidden, const float* pos_logits, const float* neg_logits,
-                      const float* save_x, const float* save_h1,
+                      const float* save_x, const float* save_h1, const float* save_aux,
                       const float* d_hidden, const float* d_pos, const float* d_neg, int fused_bce,
                       float* grad_table, float* grad_slabs,
                       float* scratch, int64_t scratch_floats,

@@ -117,6 +117,11 @@ struct MatT {           // element (r, c) of the transpose of a row-major LDS ma
   int ld;
   __device__ __forceinline__ float operator()(int r, int c) const { return p[c * ld + r]; }
 };
+struct MatTPos {        // transpose of an LDS matrix with negative entries read as zero: the sign-coded attention
+  const lds_f* p;       // probabilities (dropped entries stored negated) read as the kept ones
+  int ld;
+  __device__ __forceinline__ float operator()(int r, int c) const { return fmaxf(p[c * ld + r], 0.f); }
+};
 struct MatOnes {        // [M | 1]: column `one_col` reads 1.0 - folds a column-sum (bias gradient) into a dW GEMM
   const lds_f* p;
   int ld, one_col;
@@ -265,7 +270,11 @@ __device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int
         const int r = ((mt + j * mgroups) << 4) + (lq << 2) + e;
         if (r < sl.R) {
           float* ptr = colbase + r * rstride;
+#ifdef SRFRD_XA
+          if (false) atomicAdd(ptr, acc[j][e]);
+#else
           if (sl.rmw) atomicAdd(ptr, acc[j][e]);
+#endif
           else *ptr = acc[j][e];
         }
       }
@@ -524,9 +533,12 @@ struct OnesRow {        // A operand whose row 0 is all ones (rows 1..15 zero): 
 // once and the loops are fully unrolled (no per-element LDS round trip on the dependency chain).
 constexpr int kSMJ = 32;     // elements per lane: rows up to 128 keys
 // MASKED = true : S <- mask * P (forward).   MASKED = false: S <- P and, if S_masked != nullptr, S_masked <- mask * P
+// gsave (forward, training): the probabilities also go to global memory as [rows][LP], SIGN-CODED with the dropout
+// mask - a dropped entry is stored negated (P >= 0, so |.| is P and the sign bit is the mask; exact zeros above the
+// diagonal).  The backward pass reads them back instead of recomputing q k^T, the softmax and the mask hash.
 template <bool MASKED>
 __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld, int LP, const DropSite& ds,
-                                             lds_f* S_masked = nullptr) {
+                                             lds_f* S_masked = nullptr, float* gsave = nullptr) {
   const int q = threadIdx.x & 3, rpp = nw << 4;
   const int nj = LP >> 2;                       // elements per lane (LP is a multiple of 16)
   if (nj > kSMJ) {                              // rows longer than 4 * kSMJ keys: streaming three-pass form
@@ -544,7 +556,11 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
       s = quad_sum(s);
       for (int j = q; j < LP; j += 4) {
         float p = j <= r ? row[j] / s : 0.f;
-        if (MASKED) p *= drop_mul(ds, r, j);
+        if (MASKED) {
+          const float mul = drop_mul(ds, r, j);
+          if (gsave != nullptr) gsave[(int64_t)r * LP + j] = mul != 0.f ? p : -p;
+          p *= mul;
+        }
         row[j] = p;
         if (!MASKED && S_masked != nullptr) S_masked[r * sld + j] = p * drop_mul(ds, r, j);
       }
@@ -575,7 +591,11 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
       const int j = q + 4 * i;
       if (i < nj) {
         float p = x[i] / s;                      // exact zero above the diagonal (x = 0)
-        if (MASKED) p *= drop_mul(ds, r, j);
+        if (MASKED) {
+          const float mul = drop_mul(ds, r, j);
+          if (gsave != nullptr) gsave[(int64_t)r * LP + j] = mul != 0.f ? p : -p;
+          p *= mul;
+        }
         row[j] = p;
         if (!MASKED && S_masked != nullptr) S_masked[r * sld + j] = p * drop_mul(ds, r, j);
       }
@@ -583,23 +603,26 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
   }
 }
 
-// dS = P * (dP - sum_j dP_j P_j), dP = mask * dPd, in place in dPd; rows >= rows (padding) are zeroed up to LP rows
-__device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f* P, int rows, int sld, int LP, const DropSite& ds) {
+// dS = P * (dP - sum_j dP_j P_j), dP = mask * dPd, in place in dPd; rows >= rows (padding) are zeroed up to LP rows.
+// Pm holds the sign-coded probabilities of the forward pass (see softmax_rows): P = |Pm|, kept <=> Pm > 0
+// (a kept P that underflowed to +0 reads as dropped: both give dS = 0).  `scale` = 1 / (1 - p), or 1 without dropout.
+__device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f* Pm, int rows, int sld, int LP, float scale) {
   const int q = threadIdx.x & 3, rpp = nw << 4;
   const int nj = LP >> 2;
   if (nj > kSMJ) {                              // long rows: streaming form
     for (int r = threadIdx.x >> 2; r < LP; r += rpp) {
       lds_f* drow = dPd + r * sld;
-      const lds_f* prow = P + r * sld;
+      const lds_f* prow = Pm + r * sld;
       if (r < rows) {
         float acc = 0.f;
         for (int j = q; j <= r; j += 4) {
-          const float d = drow[j] * drop_mul(ds, r, j);
+          const float pm = prow[j];
+          const float d = pm > 0.f ? drow[j] * scale : 0.f;
           drow[j] = d;
-          acc += d * prow[j];
+          acc += d * pm;                          // (d = 0 wherever pm <= 0)
         }
         acc = quad_sum(acc);
-        for (int j = q; j < LP; j += 4) drow[j] = j <= r ? prow[j] * (drow[j] - acc) : 0.f;
+        for (int j = q; j < LP; j += 4) drow[j] = j <= r ? fabsf(prow[j]) * (drow[j] - acc) : 0.f;
       } else {
         for (int j = q; j < LP; j += 4) drow[j] = 0.f;
       }
@@ -608,7 +631,7 @@ __device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f
   }
   for (int r = threadIdx.x >> 2; r < LP; r += rpp) {
     lds_f* drow = dPd + r * sld;
-    const lds_f* prow = P + r * sld;
+    const lds_f* prow = Pm + r * sld;
     float dp[kSMJ], p[kSMJ];
     float acc = 0.f;
     const bool live = r < rows;
@@ -616,8 +639,9 @@ __device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f
     for (int i = 0; i < kSMJ; ++i) {
       const int j = q + 4 * i;
       const bool on = live && i < nj && j <= r;
-      p[i] = on ? prow[j] : 0.f;
-      dp[i] = on ? drow[j] * drop_mul(ds, r, j) : 0.f;
+      const float pm = on ? prow[j] : 0.f;
+      p[i] = fabsf(pm);
+      dp[i] = pm > 0.f ? drow[j] * scale : 0.f;
       acc += dp[i] * p[i];
     }
     acc = quad_sum(acc);

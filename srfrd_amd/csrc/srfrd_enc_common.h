@@ -22,9 +22,9 @@ struct EncArgs {
   int64_t seq0;
   float qscale;
   // forward outputs
-  float *hidden, *pos_logits, *neg_logits, *save_x, *save_h1, *loss_part;
+  float *hidden, *pos_logits, *neg_logits, *save_x, *save_h1, *save_aux, *loss_part;
   // backward inputs / outputs
-  const float *c_hidden, *c_pl, *c_nl, *c_save_x, *c_save_h1, *d_hidden, *d_pos, *d_neg;
+  const float *c_hidden, *c_pl, *c_nl, *c_save_x, *c_save_h1, *c_save_aux, *d_hidden, *d_pos, *d_neg;
   int fused_bce;
   float *grad_table, *grad_slabs;
   // SRFRD_BUF_GLOBAL build only: per-workgroup working-set scratch (floats) in global memory
@@ -37,6 +37,21 @@ struct EncArgs {
   int dbg_seq;
   int64_t dbg_slot;
 };
+
+// save_aux layout (srfrd_aux_floats): block i at i * B * aux_seq_floats; inside a block the three planes
+// r [B][L][D], o [B][L][D], Pm [B][L][LP]
+__host__ __device__ __forceinline__ int64_t aux_seq_floats(int L, int LP, int D) { return 2ll * L * D + (int64_t)L * LP; }
+struct AuxOff {
+  int64_t r, o, p;
+};
+__host__ __device__ __forceinline__ AuxOff aux_off(int i, int b, int B, int L, int LP, int D) {
+  const int64_t blk = (int64_t)i * B * aux_seq_floats(L, LP, D);
+  AuxOff f;
+  f.r = blk + (int64_t)b * L * D;
+  f.o = blk + (int64_t)B * L * D + (int64_t)b * L * D;
+  f.p = blk + 2ll * B * L * D + (int64_t)b * L * LP;
+  return f;
+}
 
 // Optimisation barrier on a wave-uniform pointer: stops LLVM from hoisting the per-call-site address arithmetic of
 // ~35 inlined GEMMs out of the sequence / block loops (which costs > 256 VGPRs and spills).

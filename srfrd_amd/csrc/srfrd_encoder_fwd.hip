@@ -51,6 +51,12 @@ using namespace srfrd;
 
 extern "C" int srfrd_long_launch_fwd(const void* args, int grid, int threads, void* stream);   // srfrd_encoder_fwd_long.hip
 
+extern "C" int64_t srfrd_aux_floats(const srfrd_layout* lay, int B, int L) {
+  if (!lay || B <= 0 || L <= 0) return SRFRD_E_ARG;
+  const Geom g = make_geom(L, lay->D);
+  return (int64_t)lay->n_blocks * B * aux_seq_floats(L, g.LP, lay->D);
+}
+
 extern "C" int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64_t* fwd_floats, int64_t* bwd_floats) {
   if (!lay || B <= 0 || L <= 0) return SRFRD_E_ARG;
   const Geom g = make_geom(L, lay->D);
@@ -97,7 +103,7 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
                                  const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
                                  double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
                                  float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
-                                 float* loss_part, float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq,
+                                 float* save_aux, float* loss_part, float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq,
                                  void* stream) {
   EncArgs a = {};
   int rc = fill_args(a, lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
@@ -106,7 +112,8 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
   if (!hidden || (pos_ids && !pos_logits) || (neg_ids && !neg_logits)) return SRFRD_E_ARG;
   if (loss_part && !(pos_ids && neg_ids)) return SRFRD_E_ARG;
   a.hidden = hidden; a.pos_logits = pos_logits; a.neg_logits = neg_logits;
-  a.save_x = save_x; a.save_h1 = save_h1; a.loss_part = loss_part;
+  if ((save_x != nullptr) != (save_h1 != nullptr) || (save_x != nullptr) != (save_aux != nullptr)) return SRFRD_E_ARG;
+  a.save_x = save_x; a.save_h1 = save_h1; a.save_aux = save_aux; a.loss_part = loss_part;
   a.dbg = dbg; a.dbg_seq = dbg_seq;
   srfrd_debug_shape(lay, L, &a.dbg_slot, nullptr);
   const Geom g = make_geom(L, lay->D);

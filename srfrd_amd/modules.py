@@ -228,14 +228,15 @@ class _SRFRDBase(nn.Module):
         nl = torch.empty(B, L, device=dev, dtype=torch.float32) if neg is not None else None
         sx = torch.empty(lay.n_blocks + 1, B, L, lay.D, device=dev, dtype=torch.float32) if save else None
         sh = torch.empty(lay.n_blocks, B, L, lay.D, device=dev, dtype=torch.float32) if save else None
+        sa = torch.empty(_lib.lib().srfrd_aux_floats(C.byref(lay), B, L), device=dev, dtype=torch.float32) if save else None
         packed = self.pack_weights()          # parameters may have been stepped since the last call
         scratch, n_scr = self._scratch_for(B, L, backward=False)
         check(_lib.lib().srfrd_encoder_fwd(
             C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(packed),
             ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
-            None, int(seq0), ptr(hidden), ptr(pl), ptr(nl), ptr(sx), ptr(sh), None, ptr(scratch), n_scr, ptr(dbg),
+            None, int(seq0), ptr(hidden), ptr(pl), ptr(nl), ptr(sx), ptr(sh), ptr(sa), None, ptr(scratch), n_scr, ptr(dbg),
             int(dbg_seq), _stream()), "srfrd_encoder_fwd")
-        return {"hidden": hidden, "pos_logits": pl, "neg_logits": nl, "save_x": sx, "save_h1": sh}
+        return {"hidden": hidden, "pos_logits": pl, "neg_logits": nl, "save_x": sx, "save_h1": sh, "save_aux": sa}
 
     def _launch_bwd(self, inp, fk, pos, pfk, neg, nfk, dropout_p, seed, out, d_hidden, d_pl, d_nl, seq0=0,
                     dbg=None, dbg_seq=0):
@@ -250,7 +251,7 @@ class _SRFRDBase(nn.Module):
             C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(self._packed),
             ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
             None, int(seq0), ptr(out["hidden"]), ptr(out["pos_logits"]), ptr(out["neg_logits"]), ptr(out["save_x"]),
-            ptr(out["save_h1"]), ptr(d_hidden), ptr(d_pl), ptr(d_nl), 0, ptr(gflat), ptr(slabs), ptr(scratch), n_scr,
+            ptr(out["save_h1"]), ptr(out["save_aux"]), ptr(d_hidden), ptr(d_pl), ptr(d_nl), 0, ptr(gflat), ptr(slabs), ptr(scratch), n_scr,
             ptr(dbg), int(dbg_seq), _stream()), "srfrd_encoder_bwd")
         check(_lib.lib().srfrd_reduce_dense(ptr(slabs), n_slabs, lay.n_dense,
                                             C.c_void_p(gflat.data_ptr() + 4 * self.n_table_pad), None, B, None, None,

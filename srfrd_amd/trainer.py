@@ -76,6 +76,7 @@ class FusedTrainer:
         self.nl = torch.empty(B, L, **f32)
         self.save_x = torch.empty(lay.n_blocks + 1, B, L, lay.D, **f32)
         self.save_h1 = torch.empty(lay.n_blocks, B, L, lay.D, **f32)
+        self.save_aux = torch.empty(_lib.lib().srfrd_aux_floats(C.byref(lay), B, L), **f32)
         self.loss_part = torch.empty(B, 3, **f32)
         self.loss = torch.zeros(1, **f32)
         self.packed = model.pack_weights()
@@ -102,11 +103,11 @@ class FusedTrainer:
         seq0 = self.rank * self.B
         check(L_.srfrd_encoder_fwd(C.byref(lay), ptr(self.flat), self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
                                    ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
-                                   ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.loss_part),
+                                   ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), ptr(self.loss_part),
                                    ptr(self.scratch), self.n_scratch, None, 0, st), "srfrd_encoder_fwd")
         check(L_.srfrd_encoder_bwd(C.byref(lay), ptr(self.flat), self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
                                    ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
-                                   ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), None, None, None, 1,
+                                   ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), None, None, None, 1,
                                    ptr(self.grad), ptr(self.slabs), ptr(self.scratch), self.n_scratch, None, 0, st),
               "srfrd_encoder_bwd")
         # single rank: the reduction also finalises the loss; with DP the loss needs the all-reduced stats first
