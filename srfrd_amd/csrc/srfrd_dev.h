@@ -122,11 +122,6 @@ struct MatTPos {        // transpose of an LDS matrix with negative entries read
   int ld;
   __device__ __forceinline__ float operator()(int r, int c) const { return fmaxf(p[c * ld + r], 0.f); }
 };
-struct MatOnes {        // [M | 1]: column `one_col` reads 1.0 - folds a column-sum (bias gradient) into a dW GEMM
-  const lds_f* p;
-  int ld, one_col;
-  __device__ __forceinline__ float operator()(int r, int c) const { return c == one_col ? 1.0f : p[r * ld + c]; }
-};
 
 // Weights pre-swizzled into MFMA B-fragment order by srfrd_pack_weights: for strip nt and 16-deep k-chunk kc, lane l
 // holds the float4 {B(16kc + 4s + (l>>4), 16nt + (l&15))}_{s=0..3}, zero outside the matrix.  One coalesced
@@ -139,11 +134,13 @@ struct PackedB {
   __device__ __forceinline__ float4 chunk(int nt, int kc, int lane) const { return p[(nt * kPackKC + kc) * 64 + lane]; }
 };
 
-// dW epilogue target: a (R x C) weight-gradient block (+ the bias gradient in column C, fed by the ones column of
-// MatOnes) in this workgroup's slab; `rmw == 0` for the first sequence of the workgroup (store), 1 afterwards (add).
+// dW epilogue target: a (R x C) weight-gradient block at float offset `w` of this workgroup's slab (+ the bias
+// gradient at offset `b`, or -1: it is column C of the product, fed by the ones column the X operand carries);
+// `rmw == 0` for the first sequence of the workgroup (store), 1 afterwards (add).  Offsets, not pointers: the
+// stores take the scalar-base + 32-bit-offset form.
 struct SlabWB {
-  float* w;
-  float* b;      // may be null
+  float* base;
+  int w, b;
   int R, C, rmw;
 };
 
@@ -257,27 +254,28 @@ __device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int
 #pragma unroll
   for (int j = 0; j < G; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   mma_group<G>(acc, a, b, (mt << 4) + li, mgroups << 4, n0 + li, 0, k_end, lq);
-  // element (r, c): r < R rows of the weight gradient; column C is the bias gradient (ones column of the B operand)
+  // element (r, c): r < R rows of the weight gradient; column C is the bias gradient
   const int c = n0 + li;
-  const bool in_w = c < sl.C, in_b = c == sl.C && sl.b != nullptr;
-  float* colbase = in_w ? sl.w + c : sl.b;
-  const int rstride = in_w ? sl.C : 1;
+  const bool in_w = c < sl.C, in_b = c == sl.C && sl.b >= 0;
   if (in_w || in_b) {
+    const int col0 = in_w ? sl.w + c : sl.b, rs = in_w ? sl.C : 1;
+    if (sl.rmw) {
 #pragma unroll
-    for (int j = 0; j < G; ++j)
+      for (int j = 0; j < G; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = ((mt + j * mgroups) << 4) + (lq << 2) + e;
-        if (r < sl.R) {
-          float* ptr = colbase + r * rstride;
-#ifdef SRFRD_XA
-          if (false) atomicAdd(ptr, acc[j][e]);
-#else
-          if (sl.rmw) atomicAdd(ptr, acc[j][e]);
-#endif
-          else *ptr = acc[j][e];
+        for (int e = 0; e < 4; ++e) {
+          const int r = ((mt + j * mgroups) << 4) + (lq << 2) + e;
+          if (r < sl.R) atomicAdd(sl.base + (col0 + r * rs), acc[j][e]);
         }
-      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = ((mt + j * mgroups) << 4) + (lq << 2) + e;
+          if (r < sl.R) sl.base[col0 + r * rs] = acc[j][e];
+        }
+    }
   }
 }
 

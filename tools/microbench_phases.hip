@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(NW * 64) mb(const float* packed, const float* 
     if (V == 0) gemm_packed(NW, MT, NT, DK, Mat{A, DS}, w, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; });
     if (V == 1) { WFrag w2 = load_wfrag(pb, bias, D, NT); gemm_packed(NW, MT, NT, DK, Mat{A, DS}, w2, [&](int r, int c, float v) { if (c < D) Cm[r * DS + c] = v; }); }
     if (V == 2) gemm_tiles<1>(NW, MT, MT, DK, Mat{A, DS}, MatT{Bm, DS}, [&](int r, int c, float v) { S[r * SLD + c] = v; });
-    if (V == 3) gemm_slab(NW, NT, NT, LP, MatT{A, DS}, MatOnes{Bm, DS, D}, SlabWB{slab + blockIdx.x * 4096, slab + blockIdx.x * 4096 + 3000, D, D, 1});
+    if (V == 3) gemm_slab(NW, NT, NT, LP, MatT{A, DS}, Mat{Bm, DS}, SlabWB{slab + blockIdx.x * 4096, 0, 3000, D, D, 1});
     if (V == 4) ln_rows(NW, A, Cm, L, DS, D, lnw, lnw + 64);
     if (V == 5) softmax_rows<true>(NW, S, L, SLD, LP, ds);
     if (V == 6) { }
