@@ -243,54 +243,97 @@ __device__ __forceinline__ WaveTiles wave_tiles(int nw, int m_tiles, int n_tiles
   return t;
 }
 
-// dW group.  The first sequence of a workgroup stores its tiles (the slab needs no zero-fill); every later one adds
-// with no-return float atomics, executed at L2: no old value travels to the CU, so nothing in the wave ever waits on
-// the slab (a load + add + store made each store wait, through the in-order vmcnt, for the one before it).  The slab
-// is private to the workgroup and a given element is always added by the same lane, in sequence order: deterministic.
-template <int G, class AL, class BL>
+// Old slab values of the (<= kMW) row tiles a wave owns in a dW GEMM.  slab_preload() requests them at the start of
+// the phase (clamped offsets, no branch per element); they become the accumulators' initial value, so the
+// read-modify-write costs the wave nothing but the registers: the loads land under the GEMMs that precede the dW
+// GEMM in the phase, the result leaves as plain stores.  (The alternatives measured slower: load + add + store
+// after the MFMA chain makes every store wait - vmcnt retires in order - for the one before it; no-return float
+// atomics execute at the memory side at ~1.3 TB/s chip-wide, 13 us of the backward at 31 MB per launch.)
+struct SlabPre {
+  float v[kMW][4];
+};
+struct SlabCol {        // this lane's column of the target: offset of row 0, row stride, validity
+  int col0, rs;
+  bool ok;
+};
+__device__ __forceinline__ SlabCol slab_col(const SlabWB& sl, int c) {
+  const bool in_w = c < sl.C, in_b = c == sl.C && sl.b >= 0;
+  SlabCol s;
+  s.col0 = in_w ? sl.w + c : (in_b ? sl.b : sl.w);
+  s.rs = in_w ? sl.C : (in_b ? 1 : 0);
+  s.ok = in_w || in_b;
+  return s;
+}
+__device__ __forceinline__ SlabPre slab_preload(int nw, int m_tiles, int n_tiles, const SlabWB& sl) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+  const WaveTiles t = wave_tiles(nw, m_tiles, n_tiles);
+  const SlabCol sc = slab_col(sl, (t.nt << 4) + li);
+  SlabPre p;
+#pragma unroll
+  for (int j = 0; j < kMW; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) p.v[j][e] = 0.f;
+  if (sl.rmw) {
+#pragma unroll
+    for (int j = 0; j < kMW; ++j)
+      if (j < t.n) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = ((t.g + j * t.mgroups) << 4) + (lq << 2) + e;
+          // clamped, unconditional: an element outside the target starts from some in-range value, and since it is
+          // never stored that is as good as zero (a select here made hipcc wait for each load before the next)
+          p.v[j][e] = sl.base[sc.col0 + min(r, sl.R - 1) * sc.rs];
+        }
+      }
+  }
+  return p;
+}
+// Makes the wave wait for a preload HERE (before the first slab store of the phase): a first use behind another dW
+// GEMM's stores would wait for their acknowledgement as well.
+__device__ __forceinline__ void slab_ready(SlabPre& p) {
+#pragma unroll
+  for (int j = 0; j < kMW; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(p.v[j][e]));
+}
+
+template <int G, int J0, class AL, class BL>
 __device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int k_end, const AL& a, const BL& b,
-                                                const SlabWB& sl, int li, int lq) {
+                                                const SlabWB& sl, const SlabPre& pre, int li, int lq) {
   f32x4 acc[G];
 #pragma unroll
-  for (int j = 0; j < G; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < G; ++j) acc[j] = f32x4{pre.v[J0 + j][0], pre.v[J0 + j][1], pre.v[J0 + j][2], pre.v[J0 + j][3]};
   mma_group<G>(acc, a, b, (mt << 4) + li, mgroups << 4, n0 + li, 0, k_end, lq);
   // element (r, c): r < R rows of the weight gradient; column C is the bias gradient
-  const int c = n0 + li;
-  const bool in_w = c < sl.C, in_b = c == sl.C && sl.b >= 0;
-  if (in_w || in_b) {
-    const int col0 = in_w ? sl.w + c : sl.b, rs = in_w ? sl.C : 1;
-    if (sl.rmw) {
+  const SlabCol sc = slab_col(sl, n0 + li);
+  if (sc.ok) {
 #pragma unroll
-      for (int j = 0; j < G; ++j)
+    for (int j = 0; j < G; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = ((mt + j * mgroups) << 4) + (lq << 2) + e;
-          if (r < sl.R) atomicAdd(sl.base + (col0 + r * rs), acc[j][e]);
-        }
-    } else {
-#pragma unroll
-      for (int j = 0; j < G; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = ((mt + j * mgroups) << 4) + (lq << 2) + e;
-          if (r < sl.R) sl.base[col0 + r * rs] = acc[j][e];
-        }
-    }
+      for (int e = 0; e < 4; ++e) {
+        const int r = ((mt + j * mgroups) << 4) + (lq << 2) + e;
+        if (r < sl.R) sl.base[sc.col0 + r * sc.rs] = acc[j][e];
+      }
   }
 }
 
 // m_tiles <= kMW * mgroups and n_tiles <= number of waves (true for every weight-gradient GEMM: <= 4 x 4 tiles)
 template <class AL, class BL>
-__device__ __forceinline__ void gemm_slab(int nw, int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl) {
+__device__ __forceinline__ void gemm_slab(int nw, int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl, const SlabPre& pre) {
   const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
   const WaveTiles t = wave_tiles(nw, m_tiles, n_tiles);
   const int n0 = t.nt << 4;
-  if (t.n >= 4) gemm_group_slab<4>(t.g, t.mgroups, n0, k_end, a, b, sl, li, lq);
+  if (t.n >= 4) gemm_group_slab<4, 0>(t.g, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
   else {
-    if (t.n >= 2) gemm_group_slab<2>(t.g, t.mgroups, n0, k_end, a, b, sl, li, lq);
-    if (t.n == 3) gemm_group_slab<1>(t.g + 2 * t.mgroups, t.mgroups, n0, k_end, a, b, sl, li, lq);
-    if (t.n == 1) gemm_group_slab<1>(t.g, t.mgroups, n0, k_end, a, b, sl, li, lq);
+    if (t.n >= 2) gemm_group_slab<2, 0>(t.g, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
+    if (t.n == 3) gemm_group_slab<1, 2>(t.g + 2 * t.mgroups, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
+    if (t.n == 1) gemm_group_slab<1, 0>(t.g, t.mgroups, n0, k_end, a, b, sl, pre, li, lq);
   }
+}
+template <class AL, class BL>
+__device__ __forceinline__ void gemm_slab(int nw, int m_tiles, int n_tiles, int k_end, AL a, BL b, SlabWB sl) {
+  SlabPre pre = slab_preload(nw, m_tiles, n_tiles, sl);
+  gemm_slab(nw, m_tiles, n_tiles, k_end, a, b, sl, pre);
 }
 
 // Weight fragments of the strip this wave owns in a packed GEMM, requested ahead of use (one phase early where the
