@@ -87,8 +87,9 @@ int srfrd_lds_bytes(const srfrd_layout* lay, int L, int64_t* fwd_bytes, int64_t*
 int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64_t* fwd_floats, int64_t* bwd_floats);
 
 /* [host] floats of the forward's `save_aux` checkpoint buffer for (B, L): per block and sequence the FFN hidden
- * activation relu(drop(.)) (L, D), the attention output P v (L, D) and the attention probabilities (L, LP = L rounded
- * up to 16), the latter sign-coded with the attention-dropout mask (a dropped entry is stored negated). */
+ * activation relu(drop(.)), the attention output P v, the scaled queries, the keys and the values (L, D each) and the
+ * attention probabilities (L, LP = L rounded up to 16), the latter sign-coded with the attention-dropout mask (a
+ * dropped entry is stored negated). */
 int64_t srfrd_aux_floats(const srfrd_layout* lay, int B, int L);
 
 /* [host] number of persistent workgroups the backward launches for batch B (= rows of `grad_slabs`). */
@@ -139,9 +140,9 @@ int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const fl
                       float* dbg, int dbg_seq, void* stream);
 
 /*
- * Fused backward of the above: LayerNorms and the q / k / v projections are recomputed in LDS from save_x / save_h1;
- * the FFN hidden activation, the attention probabilities (with their dropout mask) and the attention output are read
- * back from save_aux.  Replaces the
+ * Fused backward of the above: LayerNorms are recomputed in LDS from save_x / save_h1; q / k / v, the FFN hidden
+ * activation, the attention probabilities (with their dropout mask) and the attention output are read back from
+ * save_aux.  Replaces the
  * autograd pass behind `loss.backward()` (reference trainer.py:40).
  *
  *  fused_bce != 0: d(pos_logits) = (sigmoid(pos)-1)[pos_ids!=0], d(neg_logits) = sigmoid(neg)[pos_ids!=0]

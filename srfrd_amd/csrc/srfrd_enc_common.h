@@ -38,18 +38,21 @@ struct EncArgs {
   int64_t dbg_slot;
 };
 
-// save_aux layout (srfrd_aux_floats): block i at i * B * aux_seq_floats; inside a block the three planes
-// r [B][L][D], o [B][L][D], Pm [B][L][LP]
-__host__ __device__ __forceinline__ int64_t aux_seq_floats(int L, int LP, int D) { return 2ll * L * D + (int64_t)L * LP; }
+// save_aux layout (srfrd_aux_floats): block i at i * B * aux_seq_floats; inside a block the planes
+// r, o, q, k, v [B][L][D] and Pm [B][L][LP]
+__host__ __device__ __forceinline__ int64_t aux_seq_floats(int L, int LP, int D) { return 5ll * L * D + (int64_t)L * LP; }
 struct AuxOff {
-  int64_t r, o, p;
+  int64_t r, o, q, k, v, p;
 };
 __host__ __device__ __forceinline__ AuxOff aux_off(int i, int b, int B, int L, int LP, int D) {
-  const int64_t blk = (int64_t)i * B * aux_seq_floats(L, LP, D);
+  const int64_t blk = (int64_t)i * B * aux_seq_floats(L, LP, D), plane = (int64_t)B * L * D, seq = (int64_t)b * L * D;
   AuxOff f;
-  f.r = blk + (int64_t)b * L * D;
-  f.o = blk + (int64_t)B * L * D + (int64_t)b * L * D;
-  f.p = blk + 2ll * B * L * D + (int64_t)b * L * LP;
+  f.r = blk + seq;
+  f.o = blk + plane + seq;
+  f.q = blk + 2 * plane + seq;
+  f.k = blk + 3 * plane + seq;
+  f.v = blk + 4 * plane + seq;
+  f.p = blk + 5 * plane + (int64_t)b * L * LP;
   return f;
 }
 

@@ -63,4 +63,4 @@ def test_argument_errors_are_codes_not_crashes():
     assert lib.srfrd_topk_workspace_bytes(0, 10, 100) == 0
     lay = _lib.make_layout("SASRec", 100, 20, 50, 0, 0, 2, 1)
     assert lib.srfrd_encoder_fwd(C.byref(lay), *([None] * 9), 4, 20, 0.0, 0, None, 0, *([None] * 8), 0, None, 0, None) == -1
-    assert lib.srfrd_aux_floats(C.byref(lay), 4, 20) == 2 * 4 * (2 * 20 * 50 + 20 * 32)
+    assert lib.srfrd_aux_floats(C.byref(lay), 4, 20) == 2 * 4 * (5 * 20 * 50 + 20 * 32)
