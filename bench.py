@@ -203,7 +203,7 @@ def main():
     log(f"timed region: {elapsed:.4f} s for {args.steps} steps, loss {loss:.5f}")
 
     # ---- dominant-kernel timing: HIP events around each launch of the same K steps, eager, on the launch stream
-    kt = {"srfrd_encoder_fwd": 0.0, "srfrd_encoder_bwd": 0.0, "srfrd_adam_step": 0.0}
+    kt = {"srfrd_encoder_fwd": 0.0, "srfrd_encoder_bwd": 0.0, "srfrd_adam_pack_step": 0.0}
     if rank == 0:
         kt = time_kernels(tr, batches, min(args.steps, 50))
         log(f"kernel ms: {kt}")
@@ -271,9 +271,9 @@ def time_kernels(tr, batches, steps):
     import ctypes as C
     from srfrd_amd import _lib
     from srfrd_amd._lib import check, ptr
-    names = ["srfrd_encoder_fwd", "srfrd_encoder_bwd", "srfrd_reduce_dense", "srfrd_adam_step", "srfrd_pack_weights"]
+    names = ["srfrd_encoder_fwd", "srfrd_encoder_bwd", "srfrd_reduce_dense", "srfrd_adam_pack_step"]
     if tr.world > 1:
-        names.insert(4, "srfrd_loss_finalize")
+        names.append("srfrd_loss_finalize")
     lib = _lib.lib()
     acc = {n: 0.0 for n in names}
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(steps)]

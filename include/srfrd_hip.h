@@ -187,6 +187,17 @@ int srfrd_adam_step(float* param, float* grad, float* m, float* v, int64_t n, in
                     int64_t n_zero, double beta1, double beta2, double eps,
                     const uint32_t* state, const float* stats, void* stream);
 
+/*
+ * Fused tail of the train step: srfrd_adam_step over the whole flat vector [table | pad | dense] (n floats, the dense
+ * part starting at n_table_pad), the stepped encoder weights written straight into `packed` in both fragment forms
+ * (what srfrd_pack_weights(dense) would produce; `packed` must have been packed once before), and the optimizer-state
+ * advance of srfrd_step_begin for the NEXT step, done by the last block to finish.  `state` holds 32 words here:
+ * state[6] and state[8..23] are the ticket counters of that hand-off (zero between launches).  Replaces optimizer.step() of reference trainer.py:41.
+ */
+int srfrd_adam_pack_step(const srfrd_layout* lay, float* param, float* grad, float* m, float* v, int64_t n,
+                         int64_t n_table_pad, int64_t n_zero, double lr, double beta1, double beta2, double eps,
+                         uint32_t* state, const float* stats, float* packed, void* stream);
+
 /* loss = stats[0]/stats[2] + stats[1]/stats[2] -> loss_out[0] (reference trainer.py:36-38). */
 int srfrd_loss_finalize(const float* stats, float* loss_out, void* stream);
 

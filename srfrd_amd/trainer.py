@@ -66,7 +66,7 @@ class FusedTrainer:
         self.grad = torch.zeros(self.n_flat + 4, **f32)          # [table | dense | stats(4)]
         self.m = torch.zeros(self.n_flat, **f32)
         self.v = torch.zeros(self.n_flat, **f32)
-        self.state = torch.zeros(8, device=dev, dtype=torch.int32)
+        self.state = torch.zeros(32, device=dev, dtype=torch.int32)
         self.state[1] = int(seed) & 0x7FFFFFFF
         self.n_slabs = _lib.lib().srfrd_bwd_grid(B)
         self.slabs = torch.empty(self.n_slabs, lay.n_dense, **f32)
@@ -118,15 +118,12 @@ class FusedTrainer:
     def _enqueue_update(self):
         L_, st = _lib.lib(), self._stream()
         stats = C.c_void_p(self.grad.data_ptr() + 4 * self.n_flat)
-        check(L_.srfrd_adam_step(ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v), self.n_flat, 0, self.n_flat,
-                                 self.n_tab, self.betas[0], self.betas[1], self.eps, ptr(self.state), stats, st),
-              "srfrd_adam_step")
+        # Adam + re-pack of the stepped weights + optimizer-state advance (t, bias corrections, seed) for the next step
+        check(L_.srfrd_adam_pack_step(C.byref(self.lay), ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v),
+                                      self.n_flat, self.n_tab, self.n_tab, self.lr, self.betas[0], self.betas[1], self.eps,
+                                      ptr(self.state), stats, ptr(self.packed), st), "srfrd_adam_pack_step")
         if self.world > 1:
             check(L_.srfrd_loss_finalize(stats, ptr(self.loss), st), "srfrd_loss_finalize")
-        # re-pack the stepped weights; the same launch advances the optimizer state (t, bias corrections, seed) for the
-        # next step
-        check(L_.srfrd_pack_weights(C.byref(self.lay), self._dense_ptr(self.flat), ptr(self.packed), ptr(self.state),
-                                    self.lr, self.betas[0], self.betas[1], st), "srfrd_pack_weights")
 
     def _capture(self):
         # warm-up on a side stream (sets the LDS attributes, loads code objects), then capture

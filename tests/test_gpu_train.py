@@ -179,3 +179,22 @@ def test_generic_kernels_on_the_specialised_shape(kind, monkeypatch):
     assert abs(float(loss.detach()) - float(loss_o)) < TOL
     for k, p in model.named_parameters():
         assert maxerr(p.grad, grads_o[k]) < TOL, k
+
+
+def test_fused_tail_keeps_packed_weights_in_sync():
+    """srfrd_adam_pack_step writes the stepped weights into both fragment forms: after two fused steps the trainer's
+    packed buffer equals a fresh srfrd_pack_weights of the stepped parameters bit for bit (SRFR: last_conv included)."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, random_sd
+    cfg = O.Cfg("SRFR", 150, 24, 43, d_fake=5)
+    model = build_model(cfg, random_sd(cfg, 1)).train()
+    B = 6
+    tr = srfrd_amd.FusedTrainer(model, batch_size=B, seq_len=24, lr=1e-3, use_graph=False)
+    batch = cuda(*srfrd_amd.synthetic_batch(150, 24, B, seed=4, device="cpu"))
+    for _ in range(2):
+        tr.step(*batch)
+    torch.cuda.synchronize()
+    fused = tr.packed.clone()
+    fresh = model.pack_weights().clone()          # re-packs from the (stepped) flat parameters
+    assert torch.equal(fused, fresh)
+    assert int(tr.state[0]) == 3 and int(tr.state[6]) == 0      # state advanced once per step, ticket counter back at 0
