@@ -133,6 +133,8 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
   // 8 waves per workgroup measured fastest for the forward (95 vs 118 us at C2 with 4 waves)
   const int threads = env_threads("SRFRD_FWD_THREADS", 512);
   const bool spec = getenv("SRFRD_GENERIC") == nullptr && lay->D == 50;
+  if (spec && threads == 512 && g.LP == 64 && L == 50 && getenv("SRFRD_NO_LSPEC") == nullptr)
+    return launch_enc(encoder_fwd_kernel<50, 64, 8, 50>, grid, threads, lds, stream, a);
   if (spec && threads == 512 && g.LP == 64) return launch_enc(encoder_fwd_kernel<50, 64, 8>, grid, threads, lds, stream, a);
   if (spec && threads == 512 && g.LP == 32) return launch_enc(encoder_fwd_kernel<50, 32, 8>, grid, threads, lds, stream, a);
   if (spec && threads == 256 && g.LP == 64) return launch_enc(encoder_fwd_kernel<50, 64, 4>, grid, threads, lds, stream, a);
