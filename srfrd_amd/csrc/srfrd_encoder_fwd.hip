@@ -134,7 +134,9 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
   const int threads = env_threads("SRFRD_FWD_THREADS", 512);
   const bool spec = getenv("SRFRD_GENERIC") == nullptr && lay->D == 50;
   if (spec && threads == 512 && g.LP == 64 && L == 50 && getenv("SRFRD_NO_LSPEC") == nullptr)
-    return launch_enc(encoder_fwd_kernel<50, 64, 8, 50>, grid, threads, lds, stream, a);
+    return lay->kind == SRFRD_SASREC && getenv("SRFRD_NO_KSPEC") == nullptr
+               ? launch_enc(encoder_fwd_kernel<50, 64, 8, 50, SRFRD_SASREC>, grid, threads, lds, stream, a)
+               : launch_enc(encoder_fwd_kernel<50, 64, 8, 50>, grid, threads, lds, stream, a);
   if (spec && threads == 512 && g.LP == 64) return launch_enc(encoder_fwd_kernel<50, 64, 8>, grid, threads, lds, stream, a);
   if (spec && threads == 512 && g.LP == 32) return launch_enc(encoder_fwd_kernel<50, 32, 8>, grid, threads, lds, stream, a);
   if (spec && threads == 256 && g.LP == 64) return launch_enc(encoder_fwd_kernel<50, 64, 4>, grid, threads, lds, stream, a);
