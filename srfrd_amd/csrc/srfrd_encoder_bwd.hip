@@ -52,9 +52,13 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_tabl
   const int threads = env_threads("SRFRD_BWD_THREADS", 512);
   const bool spec = getenv("SRFRD_GENERIC") == nullptr && threads == 512 && lay->D == 50;
   if (spec && g.LP == 64 && L == 50 && getenv("SRFRD_NO_LSPEC") == nullptr)
-    return lay->kind == SRFRD_SASREC && getenv("SRFRD_NO_KSPEC") == nullptr
-               ? launch_enc(encoder_bwd_kernel<50, 64, 8, 50, SRFRD_SASREC>, grid, threads, lds, stream, a)
-               : launch_enc(encoder_bwd_kernel<50, 64, 8, 50>, grid, threads, lds, stream, a);
+  {
+    const bool train = pos_ids && neg_ids && fused_bce && !d_hidden && dropout_p > 0.0 && !dbg && getenv("SRFRD_NO_TSPEC") == nullptr;
+    if (lay->kind == SRFRD_SASREC && getenv("SRFRD_NO_KSPEC") == nullptr)
+      return train ? launch_enc(encoder_bwd_kernel<50, 64, 8, 50, SRFRD_SASREC, 1>, grid, threads, lds, stream, a)
+                   : launch_enc(encoder_bwd_kernel<50, 64, 8, 50, SRFRD_SASREC>, grid, threads, lds, stream, a);
+    return launch_enc(encoder_bwd_kernel<50, 64, 8, 50>, grid, threads, lds, stream, a);
+  }
   if (spec && g.LP == 64) return launch_enc(encoder_bwd_kernel<50, 64, 8>, grid, threads, lds, stream, a);
   if (spec && g.LP == 32) return launch_enc(encoder_bwd_kernel<50, 32, 8>, grid, threads, lds, stream, a);
   return launch_enc(encoder_bwd_kernel<0, 0, 0>, grid, threads, lds, stream, a);

@@ -134,9 +134,13 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
   const int threads = env_threads("SRFRD_FWD_THREADS", 512);
   const bool spec = getenv("SRFRD_GENERIC") == nullptr && lay->D == 50;
   if (spec && threads == 512 && g.LP == 64 && L == 50 && getenv("SRFRD_NO_LSPEC") == nullptr)
-    return lay->kind == SRFRD_SASREC && getenv("SRFRD_NO_KSPEC") == nullptr
-               ? launch_enc(encoder_fwd_kernel<50, 64, 8, 50, SRFRD_SASREC>, grid, threads, lds, stream, a)
-               : launch_enc(encoder_fwd_kernel<50, 64, 8, 50>, grid, threads, lds, stream, a);
+  {
+    const bool train = pos_ids && neg_ids && save_x && loss_part && dropout_p > 0.0 && !dbg && getenv("SRFRD_NO_TSPEC") == nullptr;
+    if (lay->kind == SRFRD_SASREC && getenv("SRFRD_NO_KSPEC") == nullptr)
+      return train ? launch_enc(encoder_fwd_kernel<50, 64, 8, 50, SRFRD_SASREC, 1>, grid, threads, lds, stream, a)
+                   : launch_enc(encoder_fwd_kernel<50, 64, 8, 50, SRFRD_SASREC>, grid, threads, lds, stream, a);
+    return launch_enc(encoder_fwd_kernel<50, 64, 8, 50>, grid, threads, lds, stream, a);
+  }
   if (spec && threads == 512 && g.LP == 64) return launch_enc(encoder_fwd_kernel<50, 64, 8>, grid, threads, lds, stream, a);
   if (spec && threads == 512 && g.LP == 32) return launch_enc(encoder_fwd_kernel<50, 32, 8>, grid, threads, lds, stream, a);
   if (spec && threads == 256 && g.LP == 64) return launch_enc(encoder_fwd_kernel<50, 64, 4>, grid, threads, lds, stream, a);
