@@ -136,9 +136,14 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
   if (spec && threads == 512 && g.LP == 64 && L == 50 && getenv("SRFRD_NO_LSPEC") == nullptr)
   {
     const bool train = pos_ids && neg_ids && save_x && loss_part && dropout_p > 0.0 && !dbg && getenv("SRFRD_NO_TSPEC") == nullptr;
-    if (lay->kind == SRFRD_SASREC && getenv("SRFRD_NO_KSPEC") == nullptr)
-      return train ? launch_enc(encoder_fwd_kernel<50, 64, 8, 50, SRFRD_SASREC, 1>, grid, threads, lds, stream, a)
-                   : launch_enc(encoder_fwd_kernel<50, 64, 8, 50, SRFRD_SASREC>, grid, threads, lds, stream, a);
+    const bool kspec = getenv("SRFRD_NO_KSPEC") == nullptr;
+#define SRFRD_LAUNCH(K, DI) (train ? launch_enc(encoder_fwd_kernel<50, 64, 8, 50, K, 1, DI>, grid, threads, lds, stream, a) \
+                                  : launch_enc(encoder_fwd_kernel<50, 64, 8, 50, K, 0, DI>, grid, threads, lds, stream, a))
+    if (kspec && lay->kind == SRFRD_SASREC) return SRFRD_LAUNCH(SRFRD_SASREC, 50);
+    if (kspec && lay->kind >= SRFRD_SRFU_B && lay->d_item == 50) return SRFRD_LAUNCH(-1, 50);
+    if (kspec && lay->kind == SRFRD_SRFRN && lay->d_item == 45) return SRFRD_LAUNCH(SRFRD_SRFRN, 45);
+    if (kspec && lay->kind == SRFRD_SRFR && lay->d_item == 45) return SRFRD_LAUNCH(SRFRD_SRFR, 45);
+#undef SRFRD_LAUNCH
     return launch_enc(encoder_fwd_kernel<50, 64, 8, 50>, grid, threads, lds, stream, a);
   }
   if (spec && threads == 512 && g.LP == 64) return launch_enc(encoder_fwd_kernel<50, 64, 8>, grid, threads, lds, stream, a);
