@@ -198,3 +198,57 @@ def test_fused_tail_keeps_packed_weights_in_sync():
     fresh = model.pack_weights().clone()          # re-packs from the (stepped) flat parameters
     assert torch.equal(fused, fresh)
     assert int(tr.state[0]) == 3 and int(tr.state[6]) == 0      # state advanced once per step, ticket counter back at 0
+
+
+def _cfg50(kind, dropout=0.0):
+    if kind == "SASRec":
+        return O.Cfg(kind, 400, 50, 50, dropout=dropout)
+    if kind in ("SRFR", "SRFRN"):
+        return O.Cfg(kind, 400, 50, 45, d_fake=5, dropout=dropout)      # the reference trainer's default 45 + 5
+    return O.Cfg(kind, 400, 50, 50, n_labels=7, dropout=dropout)
+
+
+@pytest.mark.parametrize("kind", ["SASRec", "SRFR", "SRFRN", "SRFU_B", "SRFU_R"])
+def test_bench_geometry_autograd_matches_oracle(kind):
+    """seq_len 50, hidden 50: the instantiations specialised on length, width split and kind (inference-shaped variant:
+    dropout off, upstream gradients through autograd) - outputs, loss and every gradient vs the oracle."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, maxerr, random_sd
+    cfg = _cfg50(kind)
+    sd = random_sd(cfg, 6)
+    model = build_model(cfg, sd).train()
+    batch = srfrd_amd.synthetic_batch(400, 50, 10, seed=12, device="cpu")[1:]
+    loss_o, grads_o, h_o, pl_o, nl_o = O.grads_of(cfg, sd, batch)
+    seq, rsq, pos, prs, neg, nrs = cuda(*batch)
+    h, pl, nl = model(None, seq, rsq, pos, prs, neg, nrs)
+    assert maxerr(h, h_o) < TOL and maxerr(pl, pl_o) < TOL and maxerr(nl, nl_o) < TOL
+    loss = _loss(pl, nl, pos)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_o)) < TOL
+    for k, p in model.named_parameters():
+        assert maxerr(p.grad, grads_o[k]) < TOL, k
+
+
+@pytest.mark.parametrize("kind", ["SASRec", "SRFR", "SRFRN", "SRFU_B"])
+def test_bench_geometry_fused_step_with_dropout_matches_oracle(kind):
+    """The train-mode instantiations (fused BCE, dropout 0.5, checkpoints, loss sums): two FusedTrainer steps at
+    seq_len 50 / hidden 50 vs the oracle's step with the same coordinate-hash masks (step seeds from the same base)."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, maxerr, random_sd
+    from tests.helpers import drop_kbias
+    cfg = _cfg50(kind, dropout=0.5)
+    sd = random_sd(cfg, 8)
+    model = build_model(cfg, {k: v.clone() for k, v in sd.items()}).train()
+    B, base = 12, 1234
+    tr = srfrd_amd.FusedTrainer(model, batch_size=B, seq_len=50, lr=1e-3, betas=(0.9, 0.98), seed=base, use_graph=False)
+    opt = O.Adam(sd)
+    for step in range(2):
+        batch = srfrd_amd.synthetic_batch(400, 50, B, seed=20 + step, device="cpu")
+        loss = tr.step(*cuda(*batch))
+        loss_o = O.train_step(cfg, sd, opt, batch[1:], train=True, seed=O.step_seed(base, step + 1), b0=0)
+        assert abs(float(loss.cpu()) - float(loss_o)) < TOL, step
+    msd = model.state_dict()
+    for k in sd:
+        # (two Adam steps amplify last-bit gradient noise up to ~lr on elements whose gradient is pure rounding noise)
+        d = (drop_kbias(k, msd[k].cpu(), cfg.D) - drop_kbias(k, sd[k], cfg.D)).abs()
+        assert float(d.max()) < 3e-3 and float(d.mean()) < 1e-4, k
