@@ -437,6 +437,14 @@ __device__ __forceinline__ void gemm_tiles(int nw, int m_tiles, int n_tiles, int
   for (int u = wave; u < units; u += nw) {
     const int nt = u % n_tiles, g = u / n_tiles;
     const int n0 = nt << 4;
+    if (TRI >= 2 && mgroups == 2 && m_tiles == 4) {
+      // triangular A, four row tiles, two waves per strip: tile t runs (t + 1) or (4 - t) sixteen-deep chunks, so the
+      // folded pairs {0, 3} and {1, 2} cost the same, where the strided pairs {0, 2} / {1, 3} sharing one k-range cost
+      // 13 + 13 against 9 + 9 k-steps (dv, dk) or 12 + 12 against 16 + 16 (dq) - the busier wave sets the phase
+      gemm_group<TRI, 1>(g, mgroups, n0, k_end, a, b, epi, li, lq);
+      gemm_group<TRI, 1>(3 - g, mgroups, n0, k_end, a, b, epi, li, lq);
+      continue;
+    }
     int mt = g;
     if (TRI == 1 && mt < nt) mt += ((nt - mt + mgroups - 1) / mgroups) * mgroups;   // first own row tile on/below the diagonal
     while (mt + 3 * mgroups < m_tiles) {
