@@ -172,7 +172,9 @@ int srfrd_reduce_dense(const float* grad_slabs, int n_slabs, int64_t n_dense, fl
 /*
  * Optimizer state advance (one thread): t += 1, step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t)
  * (double precision, as torch.optim.Adam computes them on the host), next dropout seed.
- *  state: uint32[8]  {t, base_seed, step_seed, -, float step_size, float bc2_sqrt, -, -}
+ *  state: uint32[32] {t, base_seed, step_seed, -, float step_size, float bc2_sqrt, ticket root, -, 16 ticket shards, -...}
+ *         (words 6 and 8..23 are the hand-off counters of srfrd_adam_pack_step, zero between launches; callers that
+ *         never use that entry point may pass 8 words)
  */
 int srfrd_step_begin(uint32_t* state, double lr, double beta1, double beta2, void* stream);
 
