@@ -16,6 +16,14 @@ __global__ void __launch_bounds__(256) reduce_dense_kernel(const float* __restri
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n_dense) {
     int w = wave;
+    for (; w + 28 < n_slabs; w += 32) {                   // eight loads in flight per lane
+      const float a0 = slabs[(int64_t)w * n_dense + i], a1 = slabs[(int64_t)(w + 4) * n_dense + i];
+      const float a2 = slabs[(int64_t)(w + 8) * n_dense + i], a3 = slabs[(int64_t)(w + 12) * n_dense + i];
+      const float a4 = slabs[(int64_t)(w + 16) * n_dense + i], a5 = slabs[(int64_t)(w + 20) * n_dense + i];
+      const float a6 = slabs[(int64_t)(w + 24) * n_dense + i], a7 = slabs[(int64_t)(w + 28) * n_dense + i];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+    }
     for (; w + 12 < n_slabs; w += 16) {
       s0 += slabs[(int64_t)w * n_dense + i];
       s1 += slabs[(int64_t)(w + 4) * n_dense + i];
