@@ -11,7 +11,7 @@ namespace srfrd {
 
 using namespace srfrd;
 
-extern "C" int srfrd_long_launch_bwd(const void* args, int grid, int threads, void* stream);   // srfrd_encoder_bwd_long.hip
+extern "C" int srfrd_long_launch_bwd(const void* args, int grid, int threads, int variant, void* stream);   // srfrd_encoder_bwd_long.hip
 
 extern "C" int srfrd_bwd_grid(int B) {
   if (B <= 0) return SRFRD_E_ARG;
@@ -47,7 +47,9 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_tabl
     if (!scratch || scratch_floats < stride * grid) return SRFRD_E_UNSUPPORTED;
     a.scratch = scratch;
     a.scratch_stride = stride;
-    return srfrd_long_launch_bwd(&a, grid, 512, stream);
+    const bool c4 = lay->kind == SRFRD_SASREC && lay->D == 50 && L == 100 && pos_ids && neg_ids && fused_bce && !d_hidden &&
+                    dropout_p > 0.0 && !dbg && getenv("SRFRD_NO_LSPEC") == nullptr && getenv("SRFRD_GENERIC") == nullptr;
+    return srfrd_long_launch_bwd(&a, grid, 512, c4 ? 1 : 0, stream);
   }
   const int threads = env_threads("SRFRD_BWD_THREADS", 512);
   const bool spec = getenv("SRFRD_GENERIC") == nullptr && threads == 512 && lay->D == 50;

@@ -146,6 +146,12 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_tabl
 #undef SRFRD_LAUNCH
     return launch_enc(encoder_fwd_kernel<50, 64, 8, 50>, grid, threads, lds, stream, a);
   }
+  if (spec && threads == 512 && L == 100 && lay->kind == SRFRD_SASREC && getenv("SRFRD_NO_LSPEC") == nullptr) {
+    // BASELINE configs[3] geometry (seq_len 100): still LDS-resident in the forward, one workgroup per CU
+    const bool train = pos_ids && neg_ids && save_x && loss_part && dropout_p > 0.0 && !dbg;
+    return train ? launch_enc(encoder_fwd_kernel<50, 112, 8, 100, SRFRD_SASREC, 1, 50>, grid, threads, lds, stream, a)
+                 : launch_enc(encoder_fwd_kernel<50, 112, 8, 100, SRFRD_SASREC, 0, 50>, grid, threads, lds, stream, a);
+  }
   if (spec && threads == 512 && g.LP == 64) return launch_enc(encoder_fwd_kernel<50, 64, 8>, grid, threads, lds, stream, a);
   if (spec && threads == 512 && g.LP == 32) return launch_enc(encoder_fwd_kernel<50, 32, 8>, grid, threads, lds, stream, a);
   if (spec && threads == 256 && g.LP == 64) return launch_enc(encoder_fwd_kernel<50, 64, 4>, grid, threads, lds, stream, a);

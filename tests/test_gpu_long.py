@@ -69,3 +69,26 @@ def test_c4_c5_length_training_matches_oracle(kind, L):
     msd = model.state_dict()
     for k in sd:
         assert maxerr(drop_kbias(k, msd[k].cpu(), cfg.D), drop_kbias(k, sd[k], cfg.D)) < 3e-4, k
+
+
+def test_c4_geometry_fused_step_with_dropout_matches_oracle():
+    """seq_len 100, hidden 50, SASRec, dropout 0.5, fused step: the compile-time-shaped instantiations of the forward
+    (LDS-resident) and of the global-scratch backward vs the oracle's step with the same masks."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, random_sd
+    from tests.helpers import drop_kbias
+    cfg = O.Cfg("SASRec", 300, 100, 50, dropout=0.5)
+    sd = random_sd(cfg, 2)
+    model = build_model(cfg, {k: v.clone() for k, v in sd.items()}).train()
+    B, base = 7, 99
+    tr = srfrd_amd.FusedTrainer(model, batch_size=B, seq_len=100, lr=1e-3, betas=(0.9, 0.98), seed=base, use_graph=False)
+    opt = O.Adam(sd)
+    for step in range(2):
+        batch = srfrd_amd.synthetic_batch(300, 100, B, seed=40 + step, device="cpu")
+        loss = tr.step(*cuda(*batch))
+        loss_o = O.train_step(cfg, sd, opt, batch[1:], train=True, seed=O.step_seed(base, step + 1), b0=0)
+        assert abs(float(loss.cpu()) - float(loss_o)) < TOL, step
+    msd = model.state_dict()
+    for k in sd:
+        d = (drop_kbias(k, msd[k].cpu(), cfg.D) - drop_kbias(k, sd[k], cfg.D)).abs()
+        assert float(d.max()) < 3e-3 and float(d.mean()) < 1e-4, k
