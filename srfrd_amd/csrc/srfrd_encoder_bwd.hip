@@ -1,7 +1,8 @@
-// Fused SRFRD encoder BACKWARD for MI355X (gfx950): recomputes each block's internals in LDS from the forward's
-// checkpoints (block inputs, post-attention residual), back-propagates through them on the fp32 matrix cores, scatters
-// item-row gradients with float atomics and accumulates every dense-parameter gradient in a per-workgroup slab.
-// Replaces the autograd pass behind `loss.backward()` (reference trainer.py:40).
+// Fused SRFRD encoder BACKWARD for MI355X (gfx950): per sequence, walks the blocks in reverse with the working set in
+// LDS - LayerNorms recomputed from the forward's checkpoints, q / k / v, the attention probabilities (sign-coded with
+// their dropout mask), the attention output and the FFN activation read back from them - back-propagates on the fp32
+// matrix cores, scatters item-row gradients with float atomics and accumulates every dense-parameter gradient in a
+// per-workgroup slab.  Replaces the autograd pass behind `loss.backward()` (reference trainer.py:40).
 #include "srfrd_enc_common.h"
 
 #include "srfrd_encoder_bwd_kernel.inc"
