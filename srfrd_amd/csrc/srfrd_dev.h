@@ -603,8 +603,9 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
         s += e;
       }
       s = quad_sum(s);
+      const float inv = 1.0f / s;                 // one division per row (a per-element IEEE division is ~10 VALU ops)
       for (int j = q; j < LP; j += 4) {
-        float p = j <= r ? row[j] / s : 0.f;
+        float p = j <= r ? row[j] * inv : 0.f;
         if (MASKED) {
           const float mul = drop_mul(ds, r, j);
           if (gsave != nullptr) gsave[(int64_t)r * LP + j] = mul != 0.f ? p : -p;
@@ -635,11 +636,12 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
       s += x[i];
     }
     s = quad_sum(s);
+    const float inv = 1.0f / s;                   // one division per row (a per-element IEEE division is ~10 VALU ops)
 #pragma unroll
     for (int i = 0; i < kSMJ; ++i) {
       const int j = q + 4 * i;
       if (i < nj) {
-        float p = x[i] / s;                      // exact zero above the diagonal (x = 0)
+        float p = x[i] * inv;                    // exact zero above the diagonal (x = 0)
         if (MASKED) {
           const float mul = drop_mul(ds, r, j);
           if (gsave != nullptr) gsave[(int64_t)r * LP + j] = mul != 0.f ? p : -p;
