@@ -252,3 +252,40 @@ def test_bench_geometry_fused_step_with_dropout_matches_oracle(kind):
         # (two Adam steps amplify last-bit gradient noise up to ~lr on elements whose gradient is pure rounding noise)
         d = (drop_kbias(k, msd[k].cpu(), cfg.D) - drop_kbias(k, sd[k], cfg.D)).abs()
         assert float(d.max()) < 3e-3 and float(d.mean()) < 1e-4, k
+
+
+@pytest.mark.parametrize("kind", ["SASRec", "SRFRN"])
+def test_more_sequences_than_workgroups_accumulate_in_the_slabs(kind):
+    """B = 600 > 2 x 256 CUs: persistent backward workgroups process up to three sequences each, so the dense
+    gradients go through the slab read-modify-write (old tile values as the MFMA accumulators' initial value) twice.
+    Gradients (autograd path) and one fused dropout step vs the oracle."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, maxerr, random_sd
+    B = 600
+    cfg = _cfg50(kind)
+    sd = random_sd(cfg, 11)
+    model = build_model(cfg, sd).train()
+    batch = srfrd_amd.synthetic_batch(400, 50, B, seed=3, device="cpu")[1:]
+    loss_o, grads_o, h_o, pl_o, nl_o = O.grads_of(cfg, sd, batch)
+    seq, rsq, pos, prs, neg, nrs = cuda(*batch)
+    h, pl, nl = model(None, seq, rsq, pos, prs, neg, nrs)
+    loss = _loss(pl, nl, pos)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_o)) < TOL
+    for k, p in model.named_parameters():
+        assert maxerr(p.grad, grads_o[k]) < TOL, k
+    # fused step with dropout (train-mode instantiation), same batch size
+    cfg_d = _cfg50(kind, dropout=0.5)
+    sd_d = random_sd(cfg_d, 12)
+    model_d = build_model(cfg_d, {k: v.clone() for k, v in sd_d.items()}).train()
+    tr = srfrd_amd.FusedTrainer(model_d, batch_size=B, seq_len=50, lr=1e-3, betas=(0.9, 0.98), seed=5, use_graph=False)
+    full = srfrd_amd.synthetic_batch(400, 50, B, seed=4, device="cpu")
+    loss_f = tr.step(*cuda(*full))
+    opt = O.Adam(sd_d)
+    loss_fo = O.train_step(cfg_d, sd_d, opt, full[1:], train=True, seed=O.step_seed(5, 1), b0=0)
+    assert abs(float(loss_f.cpu()) - float(loss_fo)) < TOL
+    msd = model_d.state_dict()
+    from tests.helpers import drop_kbias
+    for k in sd_d:
+        d = (drop_kbias(k, msd[k].cpu(), cfg_d.D) - drop_kbias(k, sd_d[k], cfg_d.D)).abs()
+        assert float(d.max()) < 2.1e-3 and float(d.mean()) < 1e-4, k
