@@ -43,7 +43,8 @@ class FusedTrainer:
     """Owns optimizer state and step buffers for one model on one GPU (one rank of a DP job)."""
 
     def __init__(self, model, batch_size: int, seq_len: int | None = None, lr: float = 1e-3, betas=(0.9, 0.98),
-                 eps: float = 1e-8, l2_emb: float = 0.0, seed: int = 42, process_group=None, use_graph: bool = True):
+                 eps: float = 1e-8, l2_emb: float = 0.0, seed: int = 42, process_group=None, use_graph: bool = True,
+                 slots: int = 1):
         if l2_emb != 0.0:
             raise NotImplementedError("fused step supports l2_emb == 0.0 (the reference default, trainer.py:124); use the "
                                       "autograd path (model(...) + torch.optim) for a non-zero L2 term")
@@ -70,7 +71,12 @@ class FusedTrainer:
         self.state[1] = int(seed) & 0x7FFFFFFF
         self.n_slabs = _lib.lib().srfrd_bwd_grid(B)
         self.slabs = torch.empty(self.n_slabs, lay.n_dense, **f32)
-        self.ids = torch.zeros(6, B, L, device=dev, dtype=torch.int64)
+        # Input ring: `slots` resident (6, B, L) id buffers.  A producer (DeviceSampler, a loader thread's H2D copy)
+        # fills slot k + 1 while step k runs and calls step_slot(k + 1): no staging copy on the step's stream.  Slot 0
+        # is also the landing buffer of step() / step_packed(), which copy their arguments in.
+        self.slots = max(1, int(slots))
+        self.ids_ring = torch.zeros(self.slots, 6, B, L, device=dev, dtype=torch.int64)
+        self.ids = self.ids_ring[0]
         self.hidden = torch.empty(B, L, lay.d_out, **f32)
         self.pl = torch.empty(B, L, **f32)
         self.nl = torch.empty(B, L, **f32)
@@ -93,9 +99,9 @@ class FusedTrainer:
     def _dense_ptr(self, base):
         return C.c_void_p(base.data_ptr() + 4 * self.n_tab)
 
-    def _enqueue_compute(self):
+    def _enqueue_compute(self, slot: int = 0):
         L_, lay, st = _lib.lib(), self.lay, self._stream()
-        ids = self.ids
+        ids = self.ids_ring[slot]
         fk = ids[1] if self.lay.kind != 0 else None
         pfk, nfk = (ids[3], ids[5]) if self.lay.kind == 2 else (None, None)
         p = self.model.dropout_rate if self.model.training else 0.0
@@ -140,15 +146,16 @@ class FusedTrainer:
             dst.copy_(src)
         self.model.pack_weights()             # the warm-up step re-packed the stepped weights: restore that too
         # thread_local capture mode: a collective backend's watchdog thread may touch the HIP runtime while we capture
-        if self.world == 1:
-            self._graph_a = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_a, capture_error_mode="thread_local"):
-                self._enqueue_compute()
-                self._enqueue_update()
-        else:
-            self._graph_a, self._graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_a, capture_error_mode="thread_local"):
-                self._enqueue_compute()
+        self._graph_a = []                    # one graph per input slot (the kernels' id pointers are baked in)
+        for slot in range(self.slots):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._enqueue_compute(slot)
+                if self.world == 1:
+                    self._enqueue_update()
+            self._graph_a.append(g)
+        if self.world > 1:
+            self._graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_b, capture_error_mode="thread_local"):
                 self._enqueue_update()
 
@@ -164,16 +171,23 @@ class FusedTrainer:
             self.ids[k].copy_(t, non_blocking=True)
         return self._run()
 
-    def _run(self):
+    def step_slot(self, slot: int) -> torch.Tensor:
+        """One train step on input slot `slot` of `ids_ring` (already filled by the caller, stream-ordered before this
+        call): the zero-copy form of step_packed()."""
+        if not 0 <= slot < self.slots:
+            raise IndexError(f"slot {slot} outside the ring of {self.slots}")
+        return self._run(slot)
+
+    def _run(self, slot: int = 0):
         if self.use_graph:
             if self._graph_a is None:
                 self._capture()
-            self._graph_a.replay()
+            self._graph_a[slot].replay()
             if self.world > 1:
                 flat_allreduce(self.grad, self.group)
                 self._graph_b.replay()
         else:
-            self._enqueue_compute()
+            self._enqueue_compute(slot)
             if self.world > 1:
                 flat_allreduce(self.grad, self.group)
             self._enqueue_update()

@@ -289,3 +289,31 @@ def test_more_sequences_than_workgroups_accumulate_in_the_slabs(kind):
     for k in sd_d:
         d = (drop_kbias(k, msd[k].cpu(), cfg_d.D) - drop_kbias(k, sd_d[k], cfg_d.D)).abs()
         assert float(d.max()) < 2.1e-3 and float(d.mean()) < 1e-4, k
+
+
+def test_input_ring_slots_match_copy_in_steps():
+    """step_slot(k) on a pre-filled ring == step_packed(batch_k): same losses and weights after four graph-replayed steps."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, random_sd
+    cfg = _cfg50("SASRec", dropout=0.5)
+    sd = random_sd(cfg, 3)
+    B = 9
+    batches = [srfrd_amd.synthetic_batch(400, 50, B, seed=7, index=i, device="cuda", packed=True)[1] for i in range(3)]
+    outs = []
+    for ring in (1, 3):
+        model = build_model(cfg, {k: v.clone() for k, v in sd.items()}).train()
+        tr = srfrd_amd.FusedTrainer(model, batch_size=B, seq_len=50, seed=11, use_graph=True, slots=ring)
+        if ring == 3:
+            for i in range(3):
+                tr.ids_ring[i].copy_(batches[i])
+        losses = []
+        for i in range(4):
+            loss = tr.step_slot(i % 3) if ring == 3 else tr.step_packed(batches[i % 3])
+            losses.append(float(loss.cpu()))
+        outs.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    # (not bit-equal: the item-table scatter adds with float atomics, so two runs differ in the last bits)
+    assert max(abs(a - b) for a, b in zip(outs[0][0], outs[1][0])) < 1e-5
+    from tests.helpers import drop_kbias
+    for k in outs[0][1]:                    # (K-bias: its gradient is rounding noise, which Adam normalises to +-lr)
+        d = (drop_kbias(k, outs[0][1][k].cpu(), cfg.D) - drop_kbias(k, outs[1][1][k].cpu(), cfg.D)).abs()
+        assert float(d.max()) < 1e-4 and float(d.mean()) < 1e-6, k
