@@ -460,7 +460,7 @@ __device__ __forceinline__ void gemm_tiles(int nw, int m_tiles, int n_tiles, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// row-wise ops: FOUR lanes (one DPP quad) per row, lane q owns columns q, q + 4, q + 8, ...  A 256-thread
+// row-wise ops: kRL (4 or 8) lanes per row, lane q owns columns q, q + kRL, q + 2 kRL, ...  With four, a 256-thread
 // workgroup therefore covers 64 rows per pass, every row's loads are in flight at once, and the reductions are two
 // DPP quad_perm adds (VALU rate) instead of six dependent ds_bpermute shuffles per row per reduction.
 // ---------------------------------------------------------------------------------------------
@@ -475,41 +475,58 @@ __device__ __forceinline__ float quad_max(float v) {
   return v;
 }
 
-constexpr int kQC = SRFRD_MAX_D / 4;    // columns per lane of a quad (D <= 64)
+// Lanes that share a row in the row-wise passes: 4 (one DPP quad) or 8 (two quads, one more row_half_mirror step).  With
+// L = 50 rows, four lanes per row keep only 200 of a workgroup's 512 lanes (waves 0-3, one per SIMD) busy; eight put
+// two half-as-long waves on every SIMD.
+#ifndef SRFRD_ROW_LANES
+#define SRFRD_ROW_LANES 8
+#endif
+constexpr int kRL = SRFRD_ROW_LANES;
+__device__ __forceinline__ float row_sum(float v) {
+  v = quad_sum(v);
+  if (kRL == 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // lane ^ 7
+  return v;
+}
+__device__ __forceinline__ float row_max(float v) {
+  v = quad_max(v);
+  if (kRL == 8) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+  return v;
+}
+constexpr int kQC = SRFRD_MAX_D / kRL;    // columns per lane (D <= 64)
 
 // Y[r] = LayerNorm(X[r]) for r < rows   (biased variance, eps inside the sqrt: torch.nn.LayerNorm)
 __device__ __forceinline__ void ln_rows(int nw, const lds_f* X, lds_f* Y, int rows, int ld, int D, const lds_f* w,
                                         const lds_f* bia) {
-  const int q = threadIdx.x & 3, rpp = nw << 4;
+  const int q = threadIdx.x & (kRL - 1), rpp = (nw << 6) / kRL;
   const float invD = 1.0f / (float)D;
   float wl[kQC], bl[kQC];
 #pragma unroll
   for (int j = 0; j < kQC; ++j) {
-    const int c = q + 4 * j;
+    const int c = q + kRL * j;
     wl[j] = c < D ? w[c] : 0.f;
     bl[j] = c < D ? bia[c] : 0.f;
   }
-  for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
+  for (int r = threadIdx.x / kRL; r < rows; r += rpp) {
     float x[kQC];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < kQC; ++j) {
-      const int c = q + 4 * j;
+      const int c = q + kRL * j;
       x[j] = c < D ? X[r * ld + c] : 0.f;
       s += x[j];
     }
-    const float mu = quad_sum(s) * invD;
+    const float mu = row_sum(s) * invD;
     float v = 0.f;
 #pragma unroll
     for (int j = 0; j < kQC; ++j) {
-      const int c = q + 4 * j;
+      const int c = q + kRL * j;
       x[j] = c < D ? x[j] - mu : 0.f;
       v += x[j] * x[j];
     }
-    const float rstd = 1.0f / sqrtf(quad_sum(v) * invD + kLnEps);
+    const float rstd = 1.0f / sqrtf(row_sum(v) * invD + kLnEps);
 #pragma unroll
     for (int j = 0; j < kQC; ++j) {
-      const int c = q + 4 * j;
+      const int c = q + kRL * j;
       if (c < D) Y[r * ld + c] = x[j] * rstd * wl[j] + bl[j];
     }
   }
@@ -522,34 +539,34 @@ __device__ __forceinline__ void ln_rows(int nw, const lds_f* X, lds_f* Y, int ro
 template <bool ACCUM>
 __device__ __forceinline__ void ln_bwd_rows(int nw, const lds_f* GY, const lds_f* X, lds_f* OUT, lds_f* GXH, int rows, int LP,
                                             int ld, int D, const lds_f* w) {
-  const int q = threadIdx.x & 3, rpp = nw << 4;
+  const int q = threadIdx.x & (kRL - 1), rpp = (nw << 6) / kRL;
   for (int i = threadIdx.x; i < (LP - rows) * ld; i += (nw << 6)) GXH[rows * ld + i] = 0.f;   // padding rows feed a k-sum
   const float invD = 1.0f / (float)D;
   float wl[kQC];
 #pragma unroll
   for (int j = 0; j < kQC; ++j) {
-    const int c = q + 4 * j;
+    const int c = q + kRL * j;
     wl[j] = c < D ? w[c] : 0.f;
   }
-  for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
+  for (int r = threadIdx.x / kRL; r < rows; r += rpp) {
     float x[kQC], g[kQC];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < kQC; ++j) {
-      const int c = q + 4 * j;
+      const int c = q + kRL * j;
       x[j] = c < D ? X[r * ld + c] : 0.f;
       g[j] = c < D ? GY[r * ld + c] : 0.f;
       s += x[j];
     }
-    const float mu = quad_sum(s) * invD;
+    const float mu = row_sum(s) * invD;
     float v = 0.f;
 #pragma unroll
     for (int j = 0; j < kQC; ++j) {
-      const int c = q + 4 * j;
+      const int c = q + kRL * j;
       x[j] = c < D ? x[j] - mu : 0.f;
       v += x[j] * x[j];
     }
-    const float rstd = 1.0f / sqrtf(quad_sum(v) * invD + kLnEps);
+    const float rstd = 1.0f / sqrtf(row_sum(v) * invD + kLnEps);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < kQC; ++j) {
@@ -558,10 +575,10 @@ __device__ __forceinline__ void ln_bwd_rows(int nw, const lds_f* GY, const lds_f
       s1 += gw;
       s2 += gw * x[j];
     }
-    const float m1 = quad_sum(s1) * invD, m2 = quad_sum(s2) * invD;
+    const float m1 = row_sum(s1) * invD, m2 = row_sum(s2) * invD;
 #pragma unroll
     for (int j = 0; j < kQC; ++j) {
-      const int c = q + 4 * j;
+      const int c = q + kRL * j;
       if (c < D) {
         const float dx = rstd * (g[j] * wl[j] - m1 - x[j] * m2);
         if (ACCUM) OUT[r * ld + c] += dx;
@@ -580,7 +597,7 @@ struct OnesRow {        // A operand whose row 0 is all ones (rows 1..15 zero): 
 // dropout multiplier into the stored probabilities (forward); the backward keeps P unmasked and masks on load.
 // A quad owns a row; each lane keeps its (up to kSMJ) elements in registers, so the row is read once and written
 // once and the loops are fully unrolled (no per-element LDS round trip on the dependency chain).
-constexpr int kSMJ = 32;     // elements per lane: rows up to 128 keys
+constexpr int kSMJ = 128 / kRL;     // elements per lane: rows up to 128 keys
 // MASKED = true : S <- mask * P (forward).   MASKED = false: S <- P and, if S_masked != nullptr, S_masked <- mask * P
 // gsave (forward, training): the probabilities also go to global memory as [rows][LP], SIGN-CODED with the dropout
 // mask - a dropped entry is stored negated (P >= 0, so |.| is P and the sign bit is the mask; exact zeros above the
@@ -588,23 +605,23 @@ constexpr int kSMJ = 32;     // elements per lane: rows up to 128 keys
 template <bool MASKED>
 __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld, int LP, const DropSite& ds,
                                              lds_f* S_masked = nullptr, float* gsave = nullptr) {
-  const int q = threadIdx.x & 3, rpp = nw << 4;
-  const int nj = LP >> 2;                       // elements per lane (LP is a multiple of 16)
+  const int q = threadIdx.x & (kRL - 1), rpp = (nw << 6) / kRL;
+  const int nj = LP / kRL;                       // elements per lane (LP is a multiple of 16)
   if (nj > kSMJ) {                              // rows longer than 4 * kSMJ keys: streaming three-pass form
-    for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
+    for (int r = threadIdx.x / kRL; r < rows; r += rpp) {
       lds_f* row = S + r * sld;
       float m = -INFINITY;
-      for (int j = q; j <= r; j += 4) m = fmaxf(m, row[j]);
-      m = quad_max(m);
+      for (int j = q; j <= r; j += kRL) m = fmaxf(m, row[j]);
+      m = row_max(m);
       float s = 0.f;
-      for (int j = q; j <= r; j += 4) {
+      for (int j = q; j <= r; j += kRL) {
         const float e = __expf(row[j] - m);
         row[j] = e;
         s += e;
       }
-      s = quad_sum(s);
+      s = row_sum(s);
       const float inv = 1.0f / s;                 // one division per row (a per-element IEEE division is ~10 VALU ops)
-      for (int j = q; j < LP; j += 4) {
+      for (int j = q; j < LP; j += kRL) {
         float p = j <= r ? row[j] * inv : 0.f;
         if (MASKED) {
           const float mul = drop_mul(ds, r, j);
@@ -617,29 +634,29 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
     }
     return;
   }
-  for (int r = threadIdx.x >> 2; r < rows; r += rpp) {
+  for (int r = threadIdx.x / kRL; r < rows; r += rpp) {
     lds_f* row = S + r * sld;
     float x[kSMJ];
     float m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < kSMJ; ++i) {
-      const int j = q + 4 * i;
+      const int j = q + kRL * i;
       x[i] = (i < nj && j <= r) ? row[j] : -INFINITY;
       m = fmaxf(m, x[i]);
     }
-    m = quad_max(m);
+    m = row_max(m);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kSMJ; ++i) {
-      const int j = q + 4 * i;
+      const int j = q + kRL * i;
       x[i] = (i < nj && j <= r) ? __expf(x[i] - m) : 0.f;      // v_exp_f32 path: ~1e-7 relative, far inside the 1e-4 bar
       s += x[i];
     }
-    s = quad_sum(s);
+    s = row_sum(s);
     const float inv = 1.0f / s;                   // one division per row (a per-element IEEE division is ~10 VALU ops)
 #pragma unroll
     for (int i = 0; i < kSMJ; ++i) {
-      const int j = q + 4 * i;
+      const int j = q + kRL * i;
       if (i < nj) {
         float p = x[i] * inv;                    // exact zero above the diagonal (x = 0)
         if (MASKED) {
@@ -658,29 +675,29 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
 // Pm holds the sign-coded probabilities of the forward pass (see softmax_rows): P = |Pm|, kept <=> Pm > 0
 // (a kept P that underflowed to +0 reads as dropped: both give dS = 0).  `scale` = 1 / (1 - p), or 1 without dropout.
 __device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f* Pm, int rows, int sld, int LP, float scale) {
-  const int q = threadIdx.x & 3, rpp = nw << 4;
-  const int nj = LP >> 2;
+  const int q = threadIdx.x & (kRL - 1), rpp = (nw << 6) / kRL;
+  const int nj = LP / kRL;
   if (nj > kSMJ) {                              // long rows: streaming form
-    for (int r = threadIdx.x >> 2; r < LP; r += rpp) {
+    for (int r = threadIdx.x / kRL; r < LP; r += rpp) {
       lds_f* drow = dPd + r * sld;
       const lds_f* prow = Pm + r * sld;
       if (r < rows) {
         float acc = 0.f;
-        for (int j = q; j <= r; j += 4) {
+        for (int j = q; j <= r; j += kRL) {
           const float pm = prow[j];
           const float d = pm > 0.f ? drow[j] * scale : 0.f;
           drow[j] = d;
           acc += d * pm;                          // (d = 0 wherever pm <= 0)
         }
-        acc = quad_sum(acc);
-        for (int j = q; j < LP; j += 4) drow[j] = j <= r ? fabsf(prow[j]) * (drow[j] - acc) : 0.f;
+        acc = row_sum(acc);
+        for (int j = q; j < LP; j += kRL) drow[j] = j <= r ? fabsf(prow[j]) * (drow[j] - acc) : 0.f;
       } else {
-        for (int j = q; j < LP; j += 4) drow[j] = 0.f;
+        for (int j = q; j < LP; j += kRL) drow[j] = 0.f;
       }
     }
     return;
   }
-  for (int r = threadIdx.x >> 2; r < LP; r += rpp) {
+  for (int r = threadIdx.x / kRL; r < LP; r += rpp) {
     lds_f* drow = dPd + r * sld;
     const lds_f* prow = Pm + r * sld;
     float dp[kSMJ], p[kSMJ];
@@ -688,17 +705,17 @@ __device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f
     const bool live = r < rows;
 #pragma unroll
     for (int i = 0; i < kSMJ; ++i) {
-      const int j = q + 4 * i;
+      const int j = q + kRL * i;
       const bool on = live && i < nj && j <= r;
       const float pm = on ? prow[j] : 0.f;
       p[i] = fabsf(pm);
       dp[i] = pm > 0.f ? drow[j] * scale : 0.f;
       acc += dp[i] * p[i];
     }
-    acc = quad_sum(acc);
+    acc = row_sum(acc);
 #pragma unroll
     for (int i = 0; i < kSMJ; ++i) {
-      const int j = q + 4 * i;
+      const int j = q + kRL * i;
       if (i < nj) drow[j] = p[i] * (dp[i] - acc);
     }
   }
