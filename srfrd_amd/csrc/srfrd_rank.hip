@@ -88,6 +88,27 @@ struct TopkArgs {
   int32_t* ccnt;        // (B) + 1 overflow flag at [B]
 };
 
+// contiguous global [rows][cols] -> LDS [rows][ld] with ITER loads in flight per thread (clamped indices, no predicate
+// between the loads): a plain `for (i = tid; ...) lds[..] = g[i]` copy pays one L2 / HBM round trip per iteration -
+// 108 of them for a 512-row chunk, which was 85 % of this kernel's time.
+template <int ITER>
+__device__ __forceinline__ void stage_rows(lds_f* dst, int ld, const float* src, int rows, int cols) {
+  const int n = rows * cols, nthr = blockDim.x, tid = threadIdx.x;
+  for (int base = 0; base < n; base += ITER * nthr) {
+    float v[ITER];
+#pragma unroll
+    for (int u = 0; u < ITER; ++u) v[u] = src[min(base + u * nthr + tid, n - 1)];
+#pragma unroll
+    for (int u = 0; u < ITER; ++u) {
+      const int i = base + u * nthr + tid;
+      if (i < n) {
+        const int r = i / cols, c = i - r * cols;
+        dst[r * ld + c] = v[u];
+      }
+    }
+  }
+}
+
 // stage a chunk of item rows and then, for this workgroup's user tiles, leave the 16 x kChunk logits tile in sS
 template <class F>
 __device__ __forceinline__ void topk_tiles(const TopkArgs& a, F&& per_tile) {
@@ -105,15 +126,34 @@ __device__ __forceinline__ void topk_tiles(const TopkArgs& a, F&& per_tile) {
   const int chunk = blockIdx.x / a.user_splits, split = blockIdx.x - chunk * a.user_splits;
   const int64_t i0 = a.item_lo + (int64_t)chunk * kChunk;
   const int n_here = (int)((a.item_hi - i0) < kChunk ? (a.item_hi - i0) : kChunk);
-  for (int idx = tid; idx < kChunk * DSi; idx += blockDim.x) {
+  for (int idx = tid; idx < kChunk * DSi; idx += blockDim.x) {          // k-padding columns and rows past the catalog
     const int r = idx / DSi, c = idx - r * DSi;
-    sE[idx] = (r < n_here && c < di) ? a.table[(i0 + r) * di + c] : 0.f;
+    if (r >= n_here || c >= di) sE[idx] = 0.f;
+  }
+  stage_rows<8>(sE, DSi, a.table + i0 * di, n_here, di);
+  for (int idx = tid; idx < 16 * (DSi - di); idx += blockDim.x) {       // k-padding columns of the user rows
+    const int r = idx / (DSi - di), c = di + idx - r * (DSi - di);
+    sH[r * DSi + c] = 0.f;
   }
   for (int u0 = split * 16; u0 < a.B; u0 += a.user_splits * 16) {
     __syncthreads();
-    for (int idx = tid; idx < 16 * DSi; idx += blockDim.x) {
-      const int r = idx / DSi, c = idx - r * DSi;
-      sH[idx] = (u0 + r < a.B && c < di) ? a.hidden[((int64_t)(u0 + r) * a.L + (a.L - 1)) * dout + c] : 0.f;
+    {                                                                   // last hidden state of 16 users: one round trip
+      float hv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(u * (int)blockDim.x + tid, 16 * di - 1);
+        const int r = i / di, c = i - r * di;
+        const int ub = min(u0 + r, a.B - 1);
+        hv[u] = a.hidden[((int64_t)ub * a.L + (a.L - 1)) * dout + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = u * (int)blockDim.x + tid;
+        if (i < 16 * di) {
+          const int r = i / di, c = i - r * di;
+          sH[r * DSi + c] = u0 + r < a.B ? hv[u] : 0.f;
+        }
+      }
     }
     if (srfrn && tid < 16) {
       float s = 0.f;
@@ -125,26 +165,119 @@ __device__ __forceinline__ void topk_tiles(const TopkArgs& a, F&& per_tile) {
       sF[tid] = s;
     }
     __syncthreads();
-    gemm_tiles<0>(nw, 1, kChunk / 16, DKi, Mat{sH, DSi}, MatT{sE, DSi}, [&](int r, int c, float v) {
-      if (srfrn) v += sF[r];
-      const bool ok = c < n_here && !(a.exclude_pad && i0 + c == 0);
-      sS[r * SLD + c] = ok ? v : -INFINITY;
+    // items on the M side (32 row tiles: a wave walks them four at a time, one hidden-state fragment feeding four
+    // independent accumulator chains), the 16 users as the single column strip; the tile lands user-major in sS
+    gemm_tiles<0>(nw, kChunk / 16, 1, DKi, Mat{sE, DSi}, MatT{sH, DSi}, [&](int r, int c, float v) {
+      if (srfrn) v += sF[c];
+      const bool ok = r < n_here && !(a.exclude_pad && i0 + r == 0);
+      sS[c * SLD + r] = ok ? v : -INFINITY;
     });
     __syncthreads();
     per_tile(u0, chunk, i0, sS, SLD);
   }
 }
 
-__global__ void __launch_bounds__(256) topk_max_kernel(const TopkArgs a) {
-  topk_tiles(a, [&](int u0, int chunk, int64_t, lds_f* sS, int SLD) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int r = wave; r < 16; r += nw) {
-      float m = -INFINITY;
-      for (int j = lane; j < kChunk; j += 64) m = fmaxf(m, sS[r * SLD + j]);
-      m = wave_max(m);
-      if (lane == 0 && u0 + r < a.B) a.cmax[(int64_t)(u0 + r) * a.n_chunks + chunk] = m;
+// The same walk for the two threshold passes, without the score tile: every logit goes from the accumulator straight
+// into elem(user_in_tile, item, value) - a running maximum (pass A) or a compare against tau (pass B) - so the
+// 16 x kChunk tile never makes the round trip through LDS.  Eight waves, the next user tile's hidden rows are
+// requested before the current tile's GEMM and land in the other half of a two-deep LDS buffer.
+template <class BEG, class ELEM, class END>
+__device__ __forceinline__ void topk_stream(const TopkArgs& a, BEG&& begin, ELEM&& elem, END&& end) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, nw = blockDim.x >> 6, nthr = blockDim.x;
+  const srfrd_layout& ly = a.ly;
+  const int di = ly.d_item, dout = ly.d_out, D = ly.D;
+  const bool srfrn = ly.kind == SRFRD_SRFRN;
+  const int DKi = (di + 3) & ~3, DSi = DKi + 2;
+  lds_f* sE = (lds_f*)smem;
+  lds_f* sH = sE + kChunk * DSi;          // [2][16][DSi]
+  lds_f* sF = sH + 2 * 16 * DSi;          // [2][16]
+  lds_f* sM = sF + 32;                    // scratch of the end() step: [nw][16]
+  const int chunk = blockIdx.x / a.user_splits, split = blockIdx.x - chunk * a.user_splits;
+  const int64_t i0 = a.item_lo + (int64_t)chunk * kChunk;
+  const int n_here = (int)((a.item_hi - i0) < kChunk ? (a.item_hi - i0) : kChunk);
+  for (int idx = tid; idx < kChunk * DSi; idx += nthr) {               // k-padding columns and rows past the catalog
+    const int r = idx / DSi, c = idx - r * DSi;
+    if (r >= n_here || c >= di) sE[idx] = 0.f;
+  }
+  stage_rows<8>(sE, DSi, a.table + i0 * di, n_here, di);
+  for (int idx = tid; idx < 2 * 16 * (DSi - di); idx += nthr) {        // k-padding columns of the user rows
+    const int r = idx / (DSi - di), c = di + idx - r * (DSi - di);
+    sH[r * DSi + c] = 0.f;
+  }
+  // hidden rows of a user tile: element e of thread tid is (user e*nthr+tid / di, channel ...); two per thread at 512 threads
+  constexpr int HIT = 4;
+  float hv[HIT];
+  float fside = 0.f;
+  auto fetch = [&](int u0) {
+#pragma unroll
+    for (int u = 0; u < HIT; ++u) {
+      const int i = min(u * nthr + tid, 16 * di - 1);
+      const int r = i / di, c = i - r * di;
+      hv[u] = a.hidden[((int64_t)min(u0 + r, a.B - 1) * a.L + (a.L - 1)) * dout + c];
     }
-  });
+    if (srfrn && tid < 16) {
+      float sacc = 0.f;
+      if (u0 + tid < a.B) {
+        const int lab = (int)a.user_label[u0 + tid];
+        for (int c = di; c < D; ++c)
+          sacc += a.hidden[((int64_t)(u0 + tid) * a.L + (a.L - 1)) * dout + c] * a.dense[ly.off_side + lab * ly.d_fake + (c - di)];
+      }
+      fside = sacc;
+    }
+  };
+  auto put = [&](int u0, int buf) {
+#pragma unroll
+    for (int u = 0; u < HIT; ++u) {
+      const int i = u * nthr + tid;
+      if (i < 16 * di) {
+        const int r = i / di, c = i - r * di;
+        sH[(buf * 16 + r) * DSi + c] = u0 + r < a.B ? hv[u] : 0.f;
+      }
+    }
+    if (srfrn && tid < 16) sF[buf * 16 + tid] = fside;
+  };
+  const int ustep = a.user_splits * 16;
+  int u0 = split * 16, cur = 0;
+  if (u0 < a.B) { fetch(u0); put(u0, 0); }
+  __syncthreads();
+  for (; u0 < a.B; u0 += ustep) {
+    const bool more = u0 + ustep < a.B;
+    if (more) fetch(u0 + ustep);
+    begin(u0);
+    const lds_f* hcur = sH + cur * 16 * DSi;
+    const lds_f* fcur = sF + cur * 16;
+    // items on the M side (a wave walks its row tiles four at a time: one hidden-state fragment, four independent
+    // accumulator chains), the 16 users as the single column strip
+    gemm_tiles<0>(nw, kChunk / 16, 1, DKi, Mat{sE, DSi}, MatT{hcur, DSi}, [&](int r, int c, float v) {
+      if (srfrn) v += fcur[c];
+      const bool ok = r < n_here && !(a.exclude_pad && i0 + r == 0);
+      elem(u0, c, i0 + r, ok ? v : -INFINITY);
+    });
+    if (more) put(u0 + ustep, cur ^ 1);
+    end(u0, chunk, sM);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+__global__ void __launch_bounds__(512) topk_max_kernel(const TopkArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float m = -INFINITY;                     // this lane's user column (lane & 15) over the row tiles of its wave
+  topk_stream(a,
+      [&](int) { m = -INFINITY; },
+      [&](int, int, int64_t, float v) { m = fmaxf(m, v); },
+      [&](int u0, int chunk, lds_f* sM) {
+        float mm = fmaxf(m, __shfl_xor(m, 16, 64));
+        mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
+        if (lane < 16) sM[wave * 16 + lane] = mm;
+        __syncthreads();
+        if (threadIdx.x < 16 && u0 + (int)threadIdx.x < a.B) {
+          float t = -INFINITY;
+          for (int w = 0; w < nw; ++w) t = fmaxf(t, sM[w * 16 + threadIdx.x]);
+          a.cmax[(int64_t)(u0 + threadIdx.x) * a.n_chunks + chunk] = t;
+        }
+      });
 }
 
 // tau[b] = k-th largest of cmax[b][:] (one wave per user; -inf if fewer than k finite maxima); also resets the cursor
@@ -180,20 +313,20 @@ __global__ void __launch_bounds__(256) topk_tau_kernel(const TopkArgs a) {
   }
 }
 
-__global__ void __launch_bounds__(256) topk_collect_kernel(const TopkArgs a) {
-  topk_tiles(a, [&](int u0, int, int64_t i0, lds_f* sS, int SLD) {
-    for (int idx = threadIdx.x; idx < 16 * kChunk; idx += blockDim.x) {
-      const int r = idx / kChunk, c = idx - r * kChunk;
-      const int b = u0 + r;
-      if (b >= a.B) continue;
-      const float v = sS[r * SLD + c];
-      if (v != -INFINITY && v >= a.tau[b]) {
-        const int slot = atomicAdd(&a.ccnt[b], 1);
-        if (slot < kCandMax) a.cand[(int64_t)b * kCandMax + slot] = Cand{v, (int32_t)(i0 + c)};
-        else a.ccnt[a.B] = 1;                     // overflow: the launcher re-runs the exhaustive path
-      }
-    }
-  });
+__global__ void __launch_bounds__(512) topk_collect_kernel(const TopkArgs a) {
+  const int li = threadIdx.x & 15;
+  float tau = INFINITY;
+  topk_stream(a,
+      [&](int u0) { tau = u0 + li < a.B ? a.tau[u0 + li] : INFINITY; },
+      [&](int u0, int c, int64_t item, float v) {
+        if (v != -INFINITY && v >= tau) {
+          const int b = u0 + c;
+          const int slot = atomicAdd(&a.ccnt[b], 1);
+          if (slot < kCandMax) a.cand[(int64_t)b * kCandMax + slot] = Cand{v, (int32_t)item};
+          else a.ccnt[a.B] = 1;                     // overflow: the launcher re-runs the exhaustive path
+        }
+      },
+      [&](int, int, lds_f*) {});
 }
 
 __global__ void __launch_bounds__(256) topk_select_kernel(const TopkArgs a, int64_t* __restrict__ topk_idx,
@@ -390,11 +523,12 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const float* item_tabl
   const int DSi = ((lay->d_item + 3) & ~3) + 2;
   const size_t lds = ((size_t)kChunk * DSi + 16 * DSi + 16 * (kChunk + 2) + 16 + kSlack) * sizeof(float);
   if (lds > (size_t)kLdsLimit) return SRFRD_E_UNSUPPORTED;
+  const size_t lds_stream = ((size_t)kChunk * DSi + 2 * 16 * DSi + 32 + 8 * 16 + kSlack) * sizeof(float);   // topk_stream
   static size_t s_attr = 0;
   if (lds > s_attr) {
     if (hipFuncSetAttribute((const void*)topk_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)topk_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)topk_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void*)topk_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stream) != hipSuccess ||
+        hipFuncSetAttribute((const void*)topk_collect_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stream) != hipSuccess)
       return SRFRD_E_DEVICE;
     s_attr = lds;
   }
@@ -414,9 +548,9 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const float* item_tabl
   if (splits < 1) splits = 1;
   a.user_splits = splits;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(topk_max_kernel, dim3(n_chunks * splits), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(topk_max_kernel, dim3(n_chunks * splits), dim3(512), lds_stream, st, a);
   hipLaunchKernelGGL(topk_tau_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(topk_collect_kernel, dim3(n_chunks * splits), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(topk_collect_kernel, dim3(n_chunks * splits), dim3(512), lds_stream, st, a);
   hipLaunchKernelGGL(topk_select_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a, topk_idx, topk_val);
   // exhaustive path, armed only if a candidate list overflowed (device-side flag: no host synchronisation)
   hipLaunchKernelGGL(topk_stage1_kernel, dim3(n_chunks), dim3(256), lds, st, *lay, item_table, dense, hidden, B, L, item_lo,
