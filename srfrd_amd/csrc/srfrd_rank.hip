@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) predict_logits_kernel(srfrd_layout ly, co
 // catalogs still fill the chip.  If a user's candidates overflow the list (mass ties), the flag makes the host
 // launcher fall back to the per-chunk selection kernels below, which are exact for any input.
 // ---------------------------------------------------------------------------------------------
-constexpr int kChunk = 512;
+constexpr int kChunk = 256;
 constexpr int kCandMax = 2048;
 
 struct Cand {
@@ -543,9 +543,18 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const float* item_tabl
   a.cand = (Cand*)(ws + topk_off(B, k, n_chunks, 3));
   Cand* fb = (Cand*)(ws + topk_off(B, k, n_chunks, 4));
   const int user_tiles = (B + 15) / 16;
-  int splits = (2 * 256 + n_chunks - 1) / n_chunks;        // aim at >= 2 workgroups per CU
-  if (splits > user_tiles) splits = user_tiles;
-  if (splits < 1) splits = 1;
+  // user tiles are split over `splits` workgroups per chunk.  Each workgroup re-stages its chunk (~7 user tiles' worth of
+  // time), and the launch runs in rounds of `slots` resident workgroups: pick the split with the smallest
+  // rounds x (staging + tiles per workgroup).
+  const int slots = 256 * (lds_stream * 2 <= (size_t)kLdsLimit ? 2 : 1);
+  int splits = 1;
+  double best = 1e30;
+  for (int sp = 1; sp <= user_tiles && sp <= 64; ++sp) {
+    const int64_t wgs = (int64_t)n_chunks * sp;
+    const double rounds = (double)((wgs + slots - 1) / slots);
+    const double cost = rounds * (7.0 + (double)((user_tiles + sp - 1) / sp));
+    if (cost < best) { best = cost; splits = sp; }
+  }
   a.user_splits = splits;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(topk_max_kernel, dim3(n_chunks * splits), dim3(512), lds_stream, st, a);
