@@ -158,26 +158,40 @@ struct SlabWB {
 // interval).  The inner body is branch-free: 4 B loads + 4G A loads are issued together, then 4G MFMAs.
 // When there are more waves than strips, the waves sharing a strip take interleaved row tiles.
 // ---------------------------------------------------------------------------------------------
+// When k is the ROW index of both underlying LDS matrices (A a transposed view, B a plain matrix: every dW GEMM, dv, dk,
+// the ones-row column sums), the lanes of one operand fetch read 16 consecutive floats of rows k, k+1, k+2, k+3: with the
+// row strides that keep the (row, k) views conflict-free (54 and 66 floats: 22 and 2 banks) those runs overlap in the
+// 32 banks.  The k-steps of a 16-deep chunk may be taken in any order, so such GEMMs pair the rows that are 8 apart in
+// a half-wave (step s reads rows s, s+8 | s+4, s+12): 8 x 22 and 8 x 2 are both 16 banks - the two runs tile the banks.
+template <class AL> struct k_is_row { static constexpr bool value = false; };
+template <> struct k_is_row<MatT> { static constexpr bool value = true; };
+template <> struct k_is_row<MatTPos> { static constexpr bool value = true; };
+template <class AL, class BL> struct k_perm { static constexpr bool value = false; };
+template <class AL> struct k_perm<AL, Mat> { static constexpr bool value = k_is_row<AL>::value; };
+
 template <int G, class AL, class BL>
 __device__ __forceinline__ void mma_group(f32x4 (&acc)[G], const AL& a, const BL& b, int mrow, int mstride, int ncol,
                                           int k0, int k1, int lq) {
+  constexpr bool KP = k_perm<AL, BL>::value;
+  const int kofs = KP ? ((lq & 1) << 3) + ((lq >> 1) << 2) : lq;      // this lane's k within step 0 of a chunk
+  constexpr int kstep = KP ? 1 : 4;                                   // ... and the distance to the next step
   const int nfull = (k1 - k0) >> 4;      // full 16-deep chunks; the fragments of chunk c+1 are requested before the
   if (nfull > 0) {                       // MFMAs of chunk c are issued (double buffering), so LDS latency is hidden
     float bv[4], av[4][G];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bv[s] = b(k0 + 4 * s + lq, ncol);
+      bv[s] = b(k0 + kstep * s + kofs, ncol);
 #pragma unroll
-      for (int j = 0; j < G; ++j) av[s][j] = a(mrow + j * mstride, k0 + 4 * s + lq);
+      for (int j = 0; j < G; ++j) av[s][j] = a(mrow + j * mstride, k0 + kstep * s + kofs);
     }
     for (int c = 0; c < nfull; ++c) {
       const int kn = k0 + (min(c + 1, nfull - 1) << 4);     // the last pass re-reads its own chunk (harmless)
       float bn[4], an[4][G];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        bn[s] = b(kn + 4 * s + lq, ncol);
+        bn[s] = b(kn + kstep * s + kofs, ncol);
 #pragma unroll
-        for (int j = 0; j < G; ++j) an[s][j] = a(mrow + j * mstride, kn + 4 * s + lq);
+        for (int j = 0; j < G; ++j) an[s][j] = a(mrow + j * mstride, kn + kstep * s + kofs);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -592,6 +606,7 @@ __device__ __forceinline__ void ln_bwd_rows(int nw, const lds_f* GY, const lds_f
 struct OnesRow {        // A operand whose row 0 is all ones (rows 1..15 zero): C row 0 = column sums of B
   __device__ __forceinline__ float operator()(int r, int) const { return r == 0 ? 1.0f : 0.0f; }
 };
+template <> struct k_is_row<OnesRow> { static constexpr bool value = true; };   // (no LDS on the A side: B decides)
 
 // causal softmax of score rows r < rows in place; keys j > r get exact zeros up to LP.  MASKED folds the attention
 // dropout multiplier into the stored probabilities (forward); the backward keeps P unmasked and masks on load.
