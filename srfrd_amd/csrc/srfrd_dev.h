@@ -296,7 +296,7 @@ __device__ __forceinline__ SlabPre slab_preload(int nw, int m_tiles, int n_tiles
           const int r = ((t.g + j * t.mgroups) << 4) + (lq << 2) + e;
           // clamped, unconditional: an element outside the target starts from some in-range value, and since it is
           // never stored that is as good as zero (a select here made hipcc wait for each load before the next)
-          p.v[j][e] = sl.base[sc.col0 + min(r, sl.R - 1) * sc.rs];
+          p.v[j][e] = sl.base[(unsigned)(sc.col0 + min(r, sl.R - 1) * sc.rs)];     // (unsigned: scalar base + 32-bit offset addressing)
         }
       }
   }
@@ -326,7 +326,7 @@ __device__ __forceinline__ void gemm_group_slab(int mt, int mgroups, int n0, int
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = ((mt + j * mgroups) << 4) + (lq << 2) + e;
-        if (r < sl.R) sl.base[sc.col0 + r * sc.rs] = acc[j][e];
+        if (r < sl.R) sl.base[(unsigned)(sc.col0 + r * sc.rs)] = acc[j][e];
       }
   }
 }

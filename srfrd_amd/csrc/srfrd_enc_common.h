@@ -111,10 +111,10 @@ struct G2L {
     for (int u = 0; u < ITER; ++u) {
       const int i = min(base + u * nthr + (int)threadIdx.x, n - 1);
       if constexpr (V2) {
-        const f32x2 t = reinterpret_cast<const f32x2*>(src)[i];
+        const f32x2 t = reinterpret_cast<const f32x2*>(src)[(unsigned)i];
         v[u][0] = t.x; v[u][1] = t.y;
       } else {
-        v[u][0] = src[i];
+        v[u][0] = src[(unsigned)i];
       }
     }
   }
