@@ -29,7 +29,8 @@ def build():
         open(f"{tmp}/srfrd_amd/csrc/{fname}", "w").write("\n".join(out))
     open(f"{tmp}/include/srfrd_hip.h", "w").write(open(os.path.join(ROOT, "include", "srfrd_hip.h")).read())
     srcs = [f for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics",
+    import __graft_entry__ as ge
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-munsafe-fp-atomics"] + ge.ENCODER_FLAGS + [
            "-DSRFRD_STAMPS", "-o", OUT] + [f"{tmp}/srfrd_amd/csrc/{f}" for f in srcs]
     subprocess.run(cmd, check=True)
     import json
