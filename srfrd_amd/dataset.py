@@ -170,9 +170,14 @@ class DeviceSampler:
         self.ptr, self.items, self.reviews = data.to_device(self.device)
         self.index = 0
 
-    def next_batch(self, packed: bool = False):
+    def next_batch(self, packed: bool = False, out: torch.Tensor | None = None):
+        """``out``: an int64 (6, B, L) device tensor to fill in place - e.g. ``trainer.ids_ring[slot]``, so the batch goes
+        from the sampler kernel straight into the fused step's input slot (``trainer.step_slot(slot)``), no copy."""
         user = torch.empty(self.B, device=self.device, dtype=torch.int64)
-        out = torch.empty(6, self.B, self.L, device=self.device, dtype=torch.int64)
+        if out is None:
+            out = torch.empty(6, self.B, self.L, device=self.device, dtype=torch.int64)
+        elif out.shape != (6, self.B, self.L) or out.dtype != torch.int64 or not out.is_contiguous() or out.device.type != "cuda":
+            raise ValueError("out must be a contiguous int64 (6, B, L) tensor on the sampler's device")
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(_lib.lib().srfrd_sample_batch(ptr(self.ptr), ptr(self.items), ptr(self.reviews), self.data.usernum,
                                             self.data.itemnum, self.B, self.L, self.seed & 0xFFFFFFFF,
