@@ -75,9 +75,11 @@ def load_csv(path: str, is_valid: bool = False) -> InteractionData:
     return partition(df["user_id"].to_numpy(), df["item_id"].to_numpy(), (df["fake_review"] == "fake").to_numpy(), is_valid)
 
 
-def eval_inputs(data: InteractionData, maxlen: int, n_neg: int = 100, seed: int = 0, users=None):
+def eval_inputs(data: InteractionData, maxlen: int, n_neg: int = 100, seed: int = 0, users=None, candidates=None):
     """For every user with a non-empty train list and a test item (utils.py:558-583): left-padded most recent ``maxlen``
     train items / review ids, and candidates [test item] + ``n_neg`` uniform items outside ``set(train) | {0}``.
+    ``candidates``: an (U, 1 + n_neg) integer array to use instead of drawing negatives (row r belongs to the r-th
+    evaluated user, column 0 must be that user's test item) - replays a recorded evaluation exactly.
     -> (user ids (U,), seq (U,L), rsq (U,L), cand (U, 1+n_neg)) int64 CPU tensors."""
     lens = data.train_len()
     if users is None:
@@ -95,6 +97,11 @@ def eval_inputs(data: InteractionData, maxlen: int, n_neg: int = 100, seed: int 
     src = np.where(ok, src, 0)
     seq[ok] = data.train_items[src[ok]]
     rsq[ok] = data.train_reviews[src[ok]]
+    if candidates is not None:
+        cand = np.asarray(candidates, dtype=np.int64)
+        if cand.ndim != 2 or cand.shape[0] != U or not (cand[:, 0] == data.test_item[users]).all():
+            raise ValueError("candidates must be (evaluated users, 1 + n_neg) with the held-out item in column 0")
+        return (torch.from_numpy(users), torch.from_numpy(seq), torch.from_numpy(rsq), torch.from_numpy(cand.copy()))
     rng = np.random.RandomState(seed)
     cand = np.zeros((U, 1 + n_neg), np.int64)
     cand[:, 0] = data.test_item[users]
@@ -121,14 +128,14 @@ def window_labels(rsq: torch.Tensor):
 
 @torch.no_grad()
 def evaluation(model, data: InteractionData, maxlen: int, batch: int = 2048, n_neg: int = 100, seed: int = 0,
-               max_users: int = 10000, with_labels: bool = False):
+               max_users: int = 10000, with_labels: bool = False, candidates=None):
     """``evaluation`` (NDCG@10, HR@10) - and with ``with_labels`` the per-label breakdowns of ``evaluation_with_label``
-    (utils.py:628-752) as {label: [HR, NDCG, count]} dicts - batched on the GPU."""
+    (utils.py:628-752) as {label: [HR, NDCG, count]} dicts - batched on the GPU.  ``candidates``: see eval_inputs."""
     from .evaluate import ranks_from_logits
     users = np.arange(1, data.usernum + 1)
     if data.usernum > max_users:                             # utils.py:551-552
         users = np.random.RandomState(seed).choice(users, max_users, replace=False)
-    uid, seq, rsq, cand = eval_inputs(data, maxlen, n_neg, seed, users)
+    uid, seq, rsq, cand = eval_inputs(data, maxlen, n_neg, seed, users, candidates)
     dev = next(model.parameters()).device
     was = model.training
     model.eval()
