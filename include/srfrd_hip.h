@@ -10,8 +10,10 @@
  *
  * Conventions
  *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked [host];
- *  - the caller owns every buffer; launchers only enqueue work on `stream` (hipStream_t passed as void*),
- *    never allocate, synchronise or touch global mutable state => graph-capturable and re-entrant;
+ *  - the caller owns every buffer; launchers only enqueue work on `stream` (hipStream_t passed as void*) and never
+ *    allocate or synchronise => graph-capturable.  The only process-wide state is a mutex-protected cache of per-device
+ *    facts (CU count, which kernels already have their > 64 KiB dynamic-LDS opt-in on which device), so launchers may
+ *    be called from several host threads and for several devices of one process;
  *  - return value: 0 = ok, < 0 = argument / capability error (SRFRD_E_*), > 0 = hipError_t of the launch;
  *  - ids are int64 (torch LongTensor, reference trainer.py:29), row-major (B, L), left-padded with 0;
  *  - all floating-point data is fp32 (dtype "f32"); integer label / rank work is exact.
@@ -206,6 +208,17 @@ int srfrd_loss_finalize(const float* stats, float* loss_out, void* stream);
 /* get_Labels (reference SRFR_model.py:546-570) and SRFRN.predict's user label (:244); labels int64 (B).
  * kind = SRFRD_SRFU_B / _F / _R, or SRFRD_SRFRN for the predict label. */
 int srfrd_user_labels(int kind, const int64_t* fake_ids, int B, int L, int64_t* labels, void* stream);
+
+/*
+ * Id validation.  The reference's nn.Embedding raises IndexError for an id outside its table (SRFR_model.py:10-12, 402-404,
+ * 590-591); the fused kernels instead CLAMP every id into range (item ids to [0, n_items], fake ids to [0, 2]) so that no
+ * input can read or scatter out of bounds, and this launcher reports the violation: err_word[0] |= 1 if any of the (up to
+ * three, each may be NULL) item-id arrays holds an id outside [0, n_items], |= 2 if any fake-id array holds one outside
+ * [0, fake_hi].  Each array has n elements.  The host reads the word when it next synchronises (srfrd_amd: check_ids()).
+ */
+int srfrd_check_ids(const int64_t* item_a, const int64_t* item_b, const int64_t* item_c,
+                    const int64_t* fake_a, const int64_t* fake_b, const int64_t* fake_c,
+                    int64_t n, int64_t n_items, int64_t fake_hi, uint32_t* err_word, void* stream);
 
 /*
  * predict (reference SRFR_model.py:144-152 and twins): logits[b][i] = <hidden[b, L-1, :], E[cand]> with

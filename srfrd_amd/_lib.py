@@ -54,6 +54,7 @@ SIGNATURES = {
     "srfrd_adam_pack_step": (_i, [_LP, _P, _P, _P, _P, _i64, _i64, _i64, _d, _d, _d, _d, _P, _P, _P, _P]),
     "srfrd_loss_finalize": (_i, [_P, _P, _P]),
     "srfrd_user_labels": (_i, [_i, _P, _i, _i, _P, _P]),
+    "srfrd_check_ids": (_i, [_P, _P, _P, _P, _P, _P, _i64, _i64, _i64, _P, _P]),
     "srfrd_predict_logits": (_i, [_LP, _P, _P, _P, _i, _i, _P, _i, _i64, _P, _P, _P]),
     "srfrd_topk_workspace_bytes": (_i64, [_i, _i, _i64]),
     "srfrd_logits_topk": (_i, [_LP, _P, _P, _P, _i, _i, _i64, _i64, _i, _P, _i, _P, _P, _P, _P]),

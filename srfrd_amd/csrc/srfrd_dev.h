@@ -61,10 +61,18 @@ __host__ __device__ __forceinline__ Geom make_geom(int L, int D) {
 
 __host__ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
+// An id as the kernels use it: clamped (in 64 bits, before the narrowing) into [0, hi], so that no input - an item id
+// beyond the model's table, a negative id, a fake id above 2 - can turn a gather into an out-of-bounds read or a
+// gradient scatter into a write over a neighbouring parameter.  Out-of-range ids are REPORTED by srfrd_check_ids (the
+// reference's nn.Embedding raises IndexError for them); the clamp only keeps the launch memory-safe until then.
+__device__ __forceinline__ int clamp_id(int64_t v, int hi) {
+  return (int)(v < 0 ? 0 : (v > (int64_t)hi ? (int64_t)hi : v));
+}
+
 // Compact, all-int32 view of srfrd_layout passed to the kernels (the full descriptor with its 8 x 12 int64 block
 // table costs hundreds of SGPRs; block offsets are affine in the block index, so they are recomputed instead).
 struct Dims {
-  int kind, d_item, d_fake, D, d_out, n_labels, n_blocks;
+  int kind, d_item, d_fake, D, d_out, n_labels, n_blocks, n_items;
   int off_pos, off_side, blk0, blk_stride, off_lc_w, off_lc_b, off_ll_w, off_ll_b, n_dense;
 };
 struct BlkOff {
@@ -734,6 +742,47 @@ __device__ __forceinline__ void softmax_bwd_rows(int nw, lds_f* dPd, const lds_f
       if (i < nj) drow[j] = p[i] * (dp[i] - acc);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// user labels (reference SRFR_model.py:546-570 get_Labels, :244 SRFRN.predict): ONE routine for the standalone
+// srfrd_user_labels kernel and the label the encoder kernels derive in place, so the two can never disagree.
+// The ratio label is torch's float32 expression floor(fl(fl(n1 / (n1 + n2)) * 10)).  Written in floating point it
+// would be at the mercy of the translation unit's relaxed flags (__graft_entry__.ENCODER_FLAGS turn the division into
+// x * rcp(y) - `#pragma clang fp reciprocal(off)` does not stop that on this compiler - and at exact-decile ratios
+// that lands one ulp below the integer: the floor drops by one, a different embedding row, not a 1e-4 error).  It is
+// therefore computed in integers: (10 n1) / (n1 + n2) equals the float32 expression for every 0 <= n1 <= n1 + n2 <= 2048
+// (checked exhaustively against numpy / torch float32; tests/test_host_logic.py repeats the check).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int user_label_from_counts(int kind, int n1, int n2) {
+  if (kind == SRFRD_SRFU_B) return (n1 < n2) ? 1 : 2;                       // round-half-even(1.5) = 2 on ties
+  if (kind == SRFRD_SRFU_F) return n1;
+  if (kind == SRFRD_SRFU_R) {
+    const int tot = n1 + n2;                                               // all-pad row: reference is 0/0; guarded to 0
+    if (tot == 0) return 0;
+    return (10 * n1) / tot;
+  }
+  return (n1 > n2) ? 2 : 1;                                                // SRFRN.predict: int() truncation, tie -> 1
+}
+// wave-uniform label of one sequence from its fake(1) / real(2) ids; n_labels > 0 clamps it into the label table (the
+// encoder's gather must stay in bounds; the reference would raise an index error instead)
+__device__ __forceinline__ int user_label_wave(int kind, const int64_t* fk_row, int L, int n_labels) {
+  const int lane = threadIdx.x & 63;
+  int n1 = 0, n2 = 0;
+  if (fk_row != nullptr)
+    for (int t = lane; t < L; t += 64) {
+      const int f = (int)fk_row[t];
+      n1 += (f == 1);
+      n2 += (f == 2);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n1 += __shfl_xor(n1, o, 64);
+    n2 += __shfl_xor(n2, o, 64);
+  }
+  int lab = user_label_from_counts(kind, n1, n2);
+  if (n_labels > 0) lab = min(max(lab, 0), n_labels - 1);
+  return lab;
 }
 
 // optimizer state advance (one thread): t += 1, Adam bias corrections in double precision as torch computes them on

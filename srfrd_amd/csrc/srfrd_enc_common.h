@@ -2,6 +2,9 @@
 // parameter cache, debug taps, host-side argument marshalling.
 #pragma once
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "srfrd_dev.h"
 
@@ -171,46 +174,21 @@ __device__ __forceinline__ void tap(const EncArgs& a, int b, int slot, const lds
   }
 }
 
-// user label of one sequence from its fake/real ids (reference SRFR_model.py:546-570); wave-uniform result
-__device__ __forceinline__ int user_label_wave(int kind, const int64_t* fk_row, int L, int n_labels) {
-  const int lane = threadIdx.x & 63;
-  int n1 = 0, n2 = 0;
-  if (fk_row != nullptr)
-    for (int t = lane; t < L; t += 64) {
-      const int f = (int)fk_row[t];
-      n1 += (f == 1);
-      n2 += (f == 2);
-    }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    n1 += __shfl_xor(n1, o, 64);
-    n2 += __shfl_xor(n2, o, 64);
-  }
-  int lab;
-  if (kind == SRFRD_SRFU_B) lab = (n1 < n2) ? 1 : 2;                       // round-half-even(1.5) = 2 on ties
-  else if (kind == SRFRD_SRFU_F) lab = n1;
-  else if (kind == SRFRD_SRFU_R) {
-    const int tot = n1 + n2;                                               // all-pad row: reference is 0/0; guarded to 0
-    lab = tot == 0 ? 0 : (int)floorf(((float)n1 / (float)tot) * 10.0f);
-  } else lab = (n1 > n2) ? 2 : 1;                                          // SRFRN.predict: int() truncation, tie -> 1
-  if (n_labels > 0) lab = min(max(lab, 0), n_labels - 1);
-  return lab;
-}
-
 // ================================================================================================
 // host side
 // ================================================================================================
-static int g_num_cu = 0;
+// CU count of the CURRENT device (cached per device: one process may drive several GPUs)
 [[maybe_unused]] static int num_cu() {
-  if (g_num_cu == 0) {
-    int dev = 0;
+  static std::mutex mu;
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cached[dev] == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      g_num_cu = prop.multiProcessorCount;
-    else
-      g_num_cu = 256;
+    cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  return g_num_cu;
+  return cached[dev];
 }
 
 // block size override for tuning runs (multiple of 64, <= 1024)
@@ -232,7 +210,7 @@ static int g_num_cu = 0;
   if (lay->kind == SRFRD_SRFRN && ((pos_ids && !pos_fake) || (neg_ids && !neg_fake))) return SRFRD_E_ARG;
   Dims& d = a.dm;
   d.kind = lay->kind; d.d_item = lay->d_item; d.d_fake = lay->d_fake; d.D = lay->D; d.d_out = lay->d_out;
-  d.n_labels = lay->n_labels; d.n_blocks = lay->n_blocks;
+  d.n_labels = lay->n_labels; d.n_blocks = lay->n_blocks; d.n_items = lay->n_items;
   d.off_pos = (int)lay->off_pos; d.off_side = (int)lay->off_side;
   d.blk0 = lay->n_blocks > 0 ? (int)lay->blk[0].ln1_w : 0;
   d.blk_stride = blk_stride_of(lay->D);
@@ -261,16 +239,23 @@ static int g_num_cu = 0;
   return 0;
 }
 
-// launch one instantiation; the > 64 KiB dynamic-LDS opt-in is per function, raised once per instantiation
+// launch one instantiation.  The > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) applies to one function on the CURRENT
+// device: it is remembered per (device, function) under a mutex, so a second GPU driven from the same process, or two
+// host threads launching concurrently, each get it set before their first launch.
 template <class K>
 static int launch_enc(K kernel, int grid, int threads, int64_t lds, void* stream, const EncArgs& a) {
-  static int64_t s_attr = 0;      // one static per instantiation of this template (= per kernel instantiation type)
-  static const void* s_fn = nullptr;
-  if (s_fn != (const void*)kernel || lds > s_attr) {
-    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return SRFRD_E_DEVICE;
-    s_fn = (const void*)kernel;
-    s_attr = lds;
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int64_t> opted;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return SRFRD_E_DEVICE;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    int64_t& have = opted[{dev, (const void*)kernel}];
+    if (lds > have) {
+      if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SRFRD_E_DEVICE;
+      have = lds;
+    }
   }
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (size_t)lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();

@@ -12,25 +12,33 @@ __global__ void __launch_bounds__(256) user_labels_kernel(int kind, const int64_
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (b >= B) return;
-  int n1 = 0, n2 = 0;
-  for (int t = lane; t < L; t += 64) {
-    const int f = (int)fake_ids[(int64_t)b * L + t];
-    n1 += (f == 1);
-    n2 += (f == 2);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    n1 += __shfl_xor(n1, o, 64);
-    n2 += __shfl_xor(n2, o, 64);
-  }
-  int lab;
-  if (kind == SRFRD_SRFU_B) lab = (n1 < n2) ? 1 : 2;
-  else if (kind == SRFRD_SRFU_F) lab = n1;
-  else if (kind == SRFRD_SRFU_R) {
-    const int tot = n1 + n2;
-    lab = tot == 0 ? 0 : (int)floorf(((float)n1 / (float)tot) * 10.0f);
-  } else lab = (n1 > n2) ? 2 : 1;
+  const int lab = user_label_wave(kind, fake_ids + (int64_t)b * L, L, 0);      // (0: the raw label, as get_Labels returns it)
   if (lane == 0) labels[b] = lab;
+}
+
+// ---------------------------------------------------------------------------------------------
+// id validation: err[0] |= 1 if any item id lies outside [0, n_items], |= 2 if any fake / label id outside [0, fake_hi].
+// The compute kernels clamp ids (memory safety); this is what turns a bad id into the IndexError the reference's
+// nn.Embedding raises - lazily, when the host reads the word.
+// ---------------------------------------------------------------------------------------------
+struct IdSets {
+  const int64_t* item[3];
+  const int64_t* fake[3];
+};
+__global__ void __launch_bounds__(256) check_ids_kernel(IdSets s, int64_t n, int64_t n_items, int64_t fake_hi, uint32_t* err) {
+  uint32_t bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (s.item[k]) { const int64_t v = s.item[k][i]; if (v < 0 || v > n_items) bad |= 1u; }
+      if (s.fake[k]) { const int64_t v = s.fake[k][i]; if (v < 0 || v > fake_hi) bad |= 2u; }
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicOr(err, bad);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -47,10 +55,10 @@ __global__ void __launch_bounds__(256) predict_logits_kernel(srfrd_layout ly, co
   const int b = (int)(w / n_cand), i = (int)(w - (int64_t)b * n_cand);
   const int dout = ly.d_out, di = ly.d_item;
   const float h = lane < dout ? hidden[((int64_t)b * L + (L - 1)) * dout + lane] : 0.f;
-  const int64_t id = cand[(int64_t)b * cand_stride + i];
+  const int64_t id = clamp_id(cand[(int64_t)b * cand_stride + i], ly.n_items);
   float e = 0.f;
   if (lane < di) e = table[id * di + lane];
-  else if (ly.kind == SRFRD_SRFRN && lane < ly.D) e = dense[ly.off_side + (int)user_label[b] * ly.d_fake + (lane - di)];
+  else if (ly.kind == SRFRD_SRFRN && lane < ly.D) e = dense[ly.off_side + clamp_id(user_label[b], 2) * ly.d_fake + (lane - di)];
   const float s = wave_sum(h * e);
   if (lane == 0) logits[w] = s;
 }
@@ -158,7 +166,7 @@ __device__ __forceinline__ void topk_tiles(const TopkArgs& a, F&& per_tile) {
     if (srfrn && tid < 16) {
       float s = 0.f;
       if (u0 + tid < a.B) {
-        const int lab = (int)a.user_label[u0 + tid];
+        const int lab = clamp_id(a.user_label[u0 + tid], 2);
         for (int c = di; c < D; ++c)
           s += a.hidden[((int64_t)(u0 + tid) * a.L + (a.L - 1)) * dout + c] * a.dense[ly.off_side + lab * ly.d_fake + (c - di)];
       }
@@ -219,7 +227,7 @@ __device__ __forceinline__ void topk_stream(const TopkArgs& a, BEG&& begin, ELEM
     if (srfrn && tid < 16) {
       float sacc = 0.f;
       if (u0 + tid < a.B) {
-        const int lab = (int)a.user_label[u0 + tid];
+        const int lab = clamp_id(a.user_label[u0 + tid], 2);
         for (int c = di; c < D; ++c)
           sacc += a.hidden[((int64_t)(u0 + tid) * a.L + (a.L - 1)) * dout + c] * a.dense[ly.off_side + lab * ly.d_fake + (c - di)];
       }
@@ -476,6 +484,17 @@ __global__ void __launch_bounds__(256) eval_rank_kernel(const float* __restrict_
 }  // namespace srfrd
 
 using namespace srfrd;
+
+extern "C" int srfrd_check_ids(const int64_t* item_a, const int64_t* item_b, const int64_t* item_c, const int64_t* fake_a,
+                               const int64_t* fake_b, const int64_t* fake_c, int64_t n, int64_t n_items, int64_t fake_hi,
+                               uint32_t* err_word, void* stream) {
+  if (!err_word || n < 0 || n_items < 0) return SRFRD_E_ARG;
+  if (n == 0 || !(item_a || item_b || item_c || fake_a || fake_b || fake_c)) return 0;
+  IdSets s{{item_a, item_b, item_c}, {fake_a, fake_b, fake_c}};
+  const int grid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+  hipLaunchKernelGGL(check_ids_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, n, n_items, fake_hi, err_word);
+  return (int)hipGetLastError();
+}
 
 extern "C" int srfrd_user_labels(int kind, const int64_t* fake_ids, int B, int L, int64_t* labels, void* stream) {
   if (!fake_ids || !labels || B <= 0 || L <= 0) return SRFRD_E_ARG;

@@ -147,6 +147,8 @@ def evaluation(model, data: InteractionData, maxlen: int, batch: int = 2048, n_n
             logits = logits.unsqueeze(0)
         ranks.append(ranks_from_logits(logits).cpu().long())
     model.train(was)
+    if hasattr(model, "check_ids"):
+        model.check_ids()                                    # an out-of-table id anywhere above raises here
     rank = torch.cat(ranks)
     hit = rank < 10
     ndcg_u = torch.where(hit, 1.0 / torch.log2(rank.double() + 2.0), torch.zeros((), dtype=torch.float64))
@@ -168,10 +170,18 @@ class DeviceSampler:
     """``WarpSampler_fr`` replacement: ``next_batch()`` returns the same 7-tuple, already on the device, generated by one
     kernel launch from the CSR histories (no worker processes, reproducible)."""
 
-    def __init__(self, data: InteractionData, batch_size: int = 64, maxlen: int = 10, seed: int = 0, device="cuda"):
+    def __init__(self, data: InteractionData, batch_size: int = 64, maxlen: int = 10, seed: int = 0, device="cuda",
+                 model=None):
+        """``model``: the module (or FusedTrainer) the batches will feed - its item table must cover ``data.itemnum``
+        (checked once here; the reference would fail at the first nn.Embedding lookup of a larger id)."""
         self.data, self.B, self.L, self.seed, self.device = data, int(batch_size), int(maxlen), int(seed), torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DeviceSampler generates batches on the ROCm GPU; there is no CPU fallback")
+        if model is not None:
+            lay = getattr(model, "lay", None) or model.layout
+            if data.itemnum > lay.n_items:
+                raise IndexError(f"the dataset holds item ids up to {data.itemnum} but the model's item table covers "
+                                 f"[0, {lay.n_items}]")
         if not bool((data.train_len()[1:] > 1).any()):
             raise ValueError("no user has more than one training interaction")
         self.ptr, self.items, self.reviews = data.to_device(self.device)

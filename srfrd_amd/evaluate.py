@@ -41,5 +41,7 @@ def evaluate_batches(model, batches):
             acc = torch.zeros(3, device=logits.device, dtype=torch.float64)
         ranks_from_logits(logits, acc)
     model.train(was_training)
+    if hasattr(model, "check_ids"):
+        model.check_ids()
     a = acc.cpu()
     return float(a[0] / a[2]), float(a[1] / a[2])

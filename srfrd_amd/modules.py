@@ -133,6 +133,11 @@ class _SRFRDBase(nn.Module):
         self._slots = None
         self._packed = None
         self._scratch = None
+        self._err = None
+        # "lazy": every call launches srfrd_check_ids on its id tensors and check_ids() (called by evaluation(), or by
+        # the user at any synchronisation point) raises; "eager": raise at the call itself like nn.Embedding does (one
+        # host sync per call); None: no validation launch (the kernels still clamp ids, so memory stays safe)
+        self.validate_ids = "lazy"
 
     # ---- layout / flat storage
     @property
@@ -259,6 +264,34 @@ class _SRFRDBase(nn.Module):
               "srfrd_reduce_dense")
         return gflat
 
+    def _validate(self, inp, fk, pos, pfk, neg, nfk):
+        if not self.validate_ids:
+            return
+        self._err_word(inp.device)
+        embeds_fake = self._kind in ("SRFR", "SRFRN")      # SRFU_* only count ids 1 / 2; SASRec ignores them
+        check(_lib.lib().srfrd_check_ids(ptr(inp), ptr(pos), ptr(neg), ptr(fk) if embeds_fake else None,
+                                         ptr(pfk), ptr(nfk), inp.numel(), self.layout.n_items, 2, ptr(self._err),
+                                         _stream()), "srfrd_check_ids")
+        if self.validate_ids == "eager":
+            self.check_ids()
+
+    def _err_word(self, dev):
+        if self._err is None or self._err.device != dev:
+            self._err = torch.zeros(1, device=dev, dtype=torch.int32)
+        return self._err
+
+    def check_ids(self):
+        """Raise IndexError if any call since the last check saw an id outside the embedding tables (what the
+        reference's nn.Embedding raises at the lookup).  Synchronises the device."""
+        if self._err is None:
+            return
+        bits = int(self._err.item())
+        if bits:
+            self._err.zero_()
+            what = " and ".join(n for b, n in ((1, f"an item id outside [0, {self.layout.n_items}]"),
+                                               (2, "a fake / review id outside [0, 2]")) if bits & b)
+            raise IndexError(f"index out of range in self: {what} (ids were clamped; results of that call are invalid)")
+
     def _prep(self, input_ids, fake_ids, positive_ids, positive_fake_ids, negative_ids, negative_fake_ids):
         self._ensure_flat()
         dev = self._flat.device
@@ -274,6 +307,7 @@ class _SRFRDBase(nn.Module):
         nfk = _ids(negative_fake_ids, dev, shp) if self._kind == "SRFRN" and neg is not None else None
         if self._kind.startswith("SRFU") and fk is None:
             raise ValueError("SRFU models need fake_ids to derive the user label")
+        self._validate(inp, fk, pos, pfk, neg, nfk)
         return inp, fk, pos, pfk, neg, nfk
 
     def forward(self, user_ids, input_ids, fake_ids, positive_ids=None, positive_fake_ids=None, negative_ids=None,
@@ -319,6 +353,11 @@ class _SRFRDBase(nn.Module):
         if cand.dim() == 2 and cand.shape[0] != B:
             raise ValueError("per-user candidates must be (B, I_c)")
         ulab = self.user_labels(fake_ids) if self._kind == "SRFRN" else None
+        if self.validate_ids:
+            check(_lib.lib().srfrd_check_ids(ptr(cand), None, None, None, None, None, cand.numel(), lay.n_items, 2,
+                                             ptr(self._err_word(dev)), _stream()), "srfrd_check_ids")
+            if self.validate_ids == "eager":
+                self.check_ids()
         logits = torch.empty(B, n_cand, device=dev, dtype=torch.float32)
         check(_lib.lib().srfrd_predict_logits(
             C.byref(lay), ptr(self._flat), C.c_void_p(self._flat.data_ptr() + 4 * self.n_table_pad), ptr(hidden), B, L,

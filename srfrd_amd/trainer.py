@@ -91,6 +91,8 @@ class FusedTrainer:
         self.use_graph = bool(use_graph)
         self._graph_a = self._graph_b = None
         self.steps_done = 0
+        self.err = torch.zeros(1, device=dev, dtype=torch.int32)   # srfrd_check_ids word of step() / step_packed() inputs
+        self._fresh = False      # packed weights known to match the parameters (see refresh())
 
     # ---- pieces -------------------------------------------------------------------------------
     def _stream(self):
@@ -160,25 +162,56 @@ class FusedTrainer:
                 self._enqueue_update()
 
     # ---- public -------------------------------------------------------------------------------
+    def refresh(self):
+        """Re-derive everything the step keeps derived from the parameters (the MFMA-fragment-ordered weight copy).  Call
+        after modifying parameters from outside the trainer - ``load_state_dict``, a re-initialisation, a manual edit;
+        the trainer's own Adam tail keeps the copy current by itself.  Done automatically before the first step."""
+        self.packed = self.model.pack_weights()
+        self._fresh = True
+
+    def _check_slot(self, slot: int = 0):
+        ids, kind = self.ids_ring[slot], self.lay.kind
+        n = self.B * self.L
+        embeds_fake = kind in (1, 2)
+        check(_lib.lib().srfrd_check_ids(ptr(ids[0]), ptr(ids[2]), ptr(ids[4]), ptr(ids[1]) if embeds_fake else None,
+                                         ptr(ids[3]) if kind == 2 else None, ptr(ids[5]) if kind == 2 else None,
+                                         n, self.lay.n_items, 2, ptr(self.err), self._stream()), "srfrd_check_ids")
+
+    def check(self):
+        """Raise IndexError if a batch given to step() / step_packed() held an id outside the embedding tables (the
+        kernels clamp such ids: memory stays safe, the step's result does not count).  Synchronises the device."""
+        bits = int(self.err.item())
+        if bits:
+            self.err.zero_()
+            raise IndexError("index out of range in self: a training batch held " + " and ".join(
+                n for b, n in ((1, f"an item id outside [0, {self.lay.n_items}]"), (2, "a fake / review id outside [0, 2]"))
+                if bits & b))
+
     def step_packed(self, batch6: torch.Tensor) -> torch.Tensor:
         """One train step on a packed int64 (6, B, L) tensor [seq, rsq, pos, prs, neg, nrs]; returns the device loss."""
         self.ids.copy_(batch6, non_blocking=True)
+        self._check_slot(0)
         return self._run()
 
     def step(self, user_ids, input_ids, fake_ids, positive_ids, positive_fake_ids, negative_ids, negative_fake_ids):
         """Same argument order as the reference model call at trainer.py:30 (``user_ids`` is unused there too)."""
         for k, t in enumerate((input_ids, fake_ids, positive_ids, positive_fake_ids, negative_ids, negative_fake_ids)):
             self.ids[k].copy_(t, non_blocking=True)
+        self._check_slot(0)
         return self._run()
 
     def step_slot(self, slot: int) -> torch.Tensor:
         """One train step on input slot `slot` of `ids_ring` (already filled by the caller, stream-ordered before this
-        call): the zero-copy form of step_packed()."""
+        call): the zero-copy form of step_packed().  The slot's ids are the producer's responsibility (DeviceSampler
+        checks its dataset against the model once, at construction); call ``_check_slot(slot)`` + ``check()`` to
+        validate a hand-filled slot."""
         if not 0 <= slot < self.slots:
             raise IndexError(f"slot {slot} outside the ring of {self.slots}")
         return self._run(slot)
 
     def _run(self, slot: int = 0):
+        if not self._fresh:
+            self.refresh()
         if self.use_graph:
             if self._graph_a is None:
                 self._capture()

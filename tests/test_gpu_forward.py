@@ -115,3 +115,99 @@ def test_eval_rank_and_metric():
     ndcg, hr = O.hr_ndcg_at_10(ro)
     a = acc.cpu()
     assert abs(float(a[0] / a[2]) - ndcg) < 1e-12 and abs(float(a[1] / a[2]) - hr) < 1e-12
+
+
+def _decile_rows(L):
+    """fake/real windows whose fake ratio sits exactly on a decile boundary (n1 / tot = k / 10), plus their neighbours:
+    the cases where a division lowered to x * rcp(y) lands one ulp under the integer and the floor drops by one."""
+    rows = []
+    for tot in range(1, L + 1):
+        for n1 in range(0, tot + 1):
+            if (10 * n1) % tot == 0 or (10 * n1 + 10) % tot == 0:
+                rows.append([0] * (L - tot) + [1] * n1 + [2] * (tot - n1))
+    return torch.tensor(rows, dtype=torch.int64)
+
+
+def test_user_labels_inside_the_encoder_match_get_labels():
+    """The label the fused forward / backward kernels derive in place (relaxed floating-point flags in those translation
+    units) selects the same ``user_label_embed`` row as ``get_Labels`` and as the reference-pinned oracle: edge matrix of
+    labels_edge.npz plus every exact-decile fake ratio up to L = 50, for all three SRFU kinds."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, maxerr, random_sd
+    z = np.load(f"{GOLDEN}/labels_edge.npz")
+    edge = torch.from_numpy(z["fake_ids"])
+    edge = torch.cat([torch.zeros(edge.shape[0], 40, dtype=torch.int64), edge], dim=1)      # left-pad to L = 50
+    rows = torch.cat([edge[1:], _decile_rows(50)])                                             # (row 0 is all-pad: 0/0 in the reference)
+    g = torch.Generator().manual_seed(5)
+    for kind, nl in (("SRFU_B", 3), ("SRFU_F", 51), ("SRFU_R", 11)):
+        cfg = O.Cfg(kind, 80, 50, 50, n_labels=nl)
+        sd = random_sd(cfg, seed=11)
+        sd["embedding_layer.user_label_embed.weight"] = torch.randn(nl, 50, generator=g)     # rows far apart: a wrong label shows
+        model = build_model(cfg, sd).eval()
+        want = O.get_labels(kind, rows)
+        assert torch.equal(model.get_Labels(rows.cuda()).cpu(), want.to(torch.int64))
+        seq = torch.randint(1, 81, rows.shape, generator=g) * (rows != 0)
+        h, _, _ = model(None, seq.cuda(), rows.cuda())
+        ho, _, _ = O.forward(cfg, sd, seq, rows)
+        assert maxerr(h, ho) < TOL, kind
+        # and through the backward kernel: the label row is where the user-label gradient lands
+        model.train()
+        for p in model.parameters():
+            p.grad = None
+        pos = torch.roll(seq, -1, 1) * (seq != 0)
+        neg = torch.randint(1, 81, rows.shape, generator=g) * (seq != 0)
+        model.dropout_rate = 0.0
+        _, pl, nl_ = model(None, seq.cuda(), rows.cuda(), pos.cuda(), None, neg.cuda(), None)
+        (pl.sum() + nl_.sum()).backward()
+        got_rows = (model.embedding_layer.user_label_embed.weight.grad.abs().sum(1) > 0).cpu()
+        live = (seq != 0).any(1)
+        expect_rows = torch.zeros(nl, dtype=torch.bool)
+        expect_rows[want[live].long()] = True
+        assert torch.equal(got_rows, expect_rows), kind
+
+
+def test_out_of_range_ids_are_clamped_and_reported():
+    """An id outside the embedding tables must neither fault nor corrupt neighbouring parameters; the reference's
+    nn.Embedding raises IndexError - lazily here (check_ids()), or at the call with validate_ids = 'eager'."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, random_sd
+    cfg = O.Cfg("SRFRN", 60, 20, 45, d_fake=5)
+    sd = random_sd(cfg, seed=2)
+    model = build_model(cfg, sd)
+    model.train()
+    model.dropout_rate = 0.0
+    _, seq, rsq, pos, prs, neg, nrs = srfrd_amd.synthetic_batch(60, 20, 16, seed=1, device="cuda")
+    before = model.flat_parameters().clone()
+    ok = model(None, seq, rsq, pos, prs, neg, nrs)
+    model.check_ids()                                               # clean batch: nothing to report
+    bad_seq, bad_neg, bad_rsq = seq.clone(), neg.clone(), rsq.clone()
+    bad_seq[3, -1] = 61                                             # one past the table
+    bad_neg[5, -2] = 2 ** 33 + 7                                    # would alias a valid row if truncated to 32 bits
+    bad_neg[6, -1] = -4
+    bad_rsq[2, -1] = 3
+    _, pl, nl = model(None, bad_seq, bad_rsq, pos, prs, bad_neg, nrs)
+    (pl.sum() + nl.sum()).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(model.flat_parameters(), before)             # nothing was written outside the gradient buffers
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    with pytest.raises(IndexError, match="item id.*fake / review id"):
+        model.check_ids()
+    model.check_ids()                                               # the word was cleared
+    model.validate_ids = "eager"
+    with pytest.raises(IndexError, match="item id"):
+        model(None, bad_seq, rsq, pos, prs, neg, nrs)
+    with pytest.raises(IndexError):
+        model.predict(None, seq[:1], rsq[:1], torch.tensor([1, 2, 999], device="cuda"))
+    model(None, seq, rsq, pos, prs, neg, nrs)                       # a clean call still passes
+    # fused trainer: step() validates its inputs; a sampler is checked against the model's table when it is wired
+    tr = srfrd_amd.FusedTrainer(model, 16, 20, use_graph=False)
+    tr.step(None, seq, rsq, pos, prs, neg, nrs)
+    tr.check()
+    tr.step(None, bad_seq, rsq, pos, prs, neg, nrs)
+    with pytest.raises(IndexError, match="item id"):
+        tr.check()
+    from srfrd_amd import dataset as DS
+    d = DS.partition([1, 1, 1, 2, 2, 2], [5, 70, 9, 3, 4, 5], [False] * 6)          # item 70 > the model's 60
+    with pytest.raises(IndexError, match="item ids up to 70"):
+        srfrd_amd.DeviceSampler(d, 4, 20, model=tr)
+    srfrd_amd.DeviceSampler(d, 4, 20)                               # unwired: no model to check against

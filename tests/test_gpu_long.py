@@ -82,13 +82,13 @@ def test_c4_geometry_fused_step_with_dropout_matches_oracle():
     model = build_model(cfg, {k: v.clone() for k, v in sd.items()}).train()
     B, base = 7, 99
     tr = srfrd_amd.FusedTrainer(model, batch_size=B, seq_len=100, lr=1e-3, betas=(0.9, 0.98), seed=base, use_graph=False)
+    from tests.helpers import assert_post_adam, oracle_step_with_grads
     opt = O.Adam(sd)
+    hist = []
     for step in range(2):
         batch = srfrd_amd.synthetic_batch(300, 100, B, seed=40 + step, device="cpu")
         loss = tr.step(*cuda(*batch))
-        loss_o = O.train_step(cfg, sd, opt, batch[1:], train=True, seed=O.step_seed(base, step + 1), b0=0)
+        loss_o, g_o = oracle_step_with_grads(cfg, sd, opt, batch[1:], train=True, seed=O.step_seed(base, step + 1), b0=0)
+        hist.append(g_o)
         assert abs(float(loss.cpu()) - float(loss_o)) < TOL, step
-    msd = model.state_dict()
-    for k in sd:
-        d = (drop_kbias(k, msd[k].cpu(), cfg.D) - drop_kbias(k, sd[k], cfg.D)).abs()
-        assert float(d.max()) < 3e-3 and float(d.mean()) < 1e-4, k
+    assert_post_adam(model.state_dict(), sd, hist, cfg.D)

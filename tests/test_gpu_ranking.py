@@ -136,7 +136,7 @@ def test_c2_fused_step_equals_autograd_step_and_learns(c2):
     tr = srfrd_amd.FusedTrainer(m1, 512, 50, use_graph=True)
     opt = torch.optim.Adam(m2.parameters(), lr=1e-3, betas=(0.9, 0.98))
     crit = torch.nn.BCEWithLogitsLoss()
-    losses = []
+    losses, hist = [], []
     for step in range(3):
         l1 = tr.step(u, seq, rsq, pos, prs, neg, nrs)
         h, pl, nl = m2(u, seq, rsq, pos, prs, neg, nrs)
@@ -144,18 +144,21 @@ def test_c2_fused_step_equals_autograd_step_and_learns(c2):
         l2 = crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
         opt.zero_grad()
         l2.backward()
+        hist.append({k: p.grad.detach().clone() for k, p in m2.named_parameters()})
         opt.step()
         assert abs(float(l1) - float(l2.detach())) < 1e-5
         losses.append(float(l1))
     assert losses[2] < losses[0]                                                  # it trains
-    # Weights: Adam divides by sqrt(v), so an element whose gradient is at rounding-noise level moves by +-O(lr) per step
-    # with a noise-determined sign (see tests/helpers.drop_kbias); the two paths differ in summation order (1/count
-    # applied before vs after the backward, float-atomic order).  Hence: bounded by 3 steps * lr everywhere, and equal
-    # to ~1e-6 on average.
+    # Weights, element-wise (tests/helpers.adam_tolerance): 1e-4 or tighter wherever the gradient is real, relaxing to
+    # 3 steps * lr only for elements whose gradient is rounding noise (Adam normalises the magnitude away, so their sign -
+    # which depends on summation order: 1 / count applied before vs after the backward, float-atomic order - is the step)
+    from tests.helpers import adam_tolerance
     sd1, sd2 = m1.state_dict(), m2.state_dict()
     for k in sd1:
-        d = (sd1[k] - sd2[k]).abs()
-        assert float(d.max()) < 3.1e-3 and float(d.mean()) < 1e-4, k
+        d = (sd1[k] - sd2[k]).abs().double().cpu()
+        tol = adam_tolerance([g[k].cpu() for g in hist])
+        bad = d > tol
+        assert not bool(bad.any()), (k, float(d[bad].max()), int(bad.sum()))
 
 
 def test_c2_untrained_hit_rate_is_chance(c2):

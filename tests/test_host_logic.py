@@ -53,11 +53,22 @@ def test_srfu_base_class_is_abstract_like_the_reference():
         m.get_Labels(torch.zeros(1, 5, dtype=torch.int64))
 
 
-def test_unsupported_geometry_is_rejected():
+def test_unsupported_geometry_is_described_by_the_layout():
+    """(the rejection itself needs a device: tests/test_gpu_train.py::test_unsupported_geometry_is_rejected)"""
     m = srfrd_amd.SASRec(10, 5, 50, 0.0, 1, 2, "cpu")      # two heads
     assert m.layout.n_heads == 2
     big = srfrd_amd.SASRec(10, 5, 128, 0.0, 1, 1, "cpu")   # wider than the fused kernels cover
     assert big.layout.D == 128
+
+
+def test_ratio_label_integer_form_equals_the_float32_expression():
+    """csrc/srfrd_dev.h computes SRFU_R's label as (10 n1) / (n1 + n2) in integers; the reference (SRFR_model.py:567-568)
+    evaluates floor(n1 / (n1 + n2) * 10) in float32.  Equal for every count pair a sequence of up to 2048 positions can
+    produce - so the kernels need no floating-point division that compiler flags could loosen."""
+    for tot in range(1, 2049):
+        n1 = torch.arange(0, tot + 1)
+        ref = torch.floor(n1 / torch.full_like(n1, tot) * 10).int()          # the reference's expression, verbatim dtype flow
+        assert torch.equal(ref.long(), (10 * n1) // tot), tot
 
 
 def test_synthetic_batch_layout():
