@@ -134,7 +134,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="exploration only; the contract line is C2")
@@ -178,7 +178,8 @@ def main():
     # eight synthetic batches resident in the trainer's input ring before the timed region starts (the contract's
     # "inputs already in HBM"): each step consumes one slot in place, as it would a slot a device sampler just filled
     ring = 1 if os.environ.get("SRFRD_BENCH_COPY") else 8
-    tr = srfrd_amd.FusedTrainer(model, B, L, lr=1e-3, betas=(0.9, 0.98), seed=42, use_graph=not args.no_graph, slots=ring)
+    tr = srfrd_amd.FusedTrainer(model, B, L, lr=1e-3, betas=(0.9, 0.98), seed=42, use_graph=not args.no_graph, slots=ring,
+                                exchange=os.environ.get("SRFRD_DP_EXCHANGE", "sharded"))
     batches = [srfrd_amd.synthetic_batch(cfg["n_items"], L, B, seed=1, index=i, rank=rank, device=dev, packed=True)[1]
                for i in range(8)]
     if ring == 8:
@@ -210,7 +211,7 @@ def main():
     log(f"timed region: {elapsed:.4f} s for {args.steps} steps, loss {loss:.5f}")
 
     # ---- dominant-kernel timing: HIP events around each launch of the same K steps, eager, on the launch stream
-    kt = {"srfrd_encoder_fwd": 0.0, "srfrd_encoder_bwd": 0.0, "srfrd_adam_pack_step": 0.0}
+    kt = {"srfrd_encoder_fwd": 0.0, "srfrd_encoder_bwd": 0.0}
     if rank == 0:
         kt = time_kernels(tr, batches, min(args.steps, 50))
         log(f"kernel ms: {kt}")
@@ -232,7 +233,7 @@ def main():
             "config": {"workload": "C2: SASRec train step (fwd + masked BCE + bwd + dense Adam), 50k items, seq_len 50, "
                                    "batch 512 per GPU, hidden 50, 2 blocks, 1 head, dropout 0.5",
                        "global_batch": world * B, "seq_len": L, "n_items": cfg["n_items"],
-                       "parallelism": f"dp{world}", "graph": not args.no_graph, "final_loss": loss},
+                       "parallelism": f"dp{world}", "exchange": tr.mode, "graph": not args.no_graph, "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
                          "avg_kernel_ms": kt[dom], "algorithmic_flops_per_launch": dom_flops,
@@ -278,8 +279,11 @@ def time_kernels(tr, batches, steps):
     import ctypes as C
     from srfrd_amd import _lib
     from srfrd_amd._lib import check, ptr
-    names = ["srfrd_encoder_fwd", "srfrd_encoder_bwd", "srfrd_reduce_dense", "srfrd_adam_pack_step"]
-    if tr.world > 1:
+    names = ["srfrd_encoder_fwd", "srfrd_encoder_bwd", "srfrd_reduce_dense"]
+    local_update = tr.mode != "sharded"        # (the sharded update needs the collectives around it: compute kernels only)
+    if local_update:
+        names.append("srfrd_adam_pack_step")
+    if tr.mode == "allreduce":
         names.append("srfrd_loss_finalize")
     lib = _lib.lib()
     acc = {n: 0.0 for n in names}
@@ -303,7 +307,8 @@ def time_kernels(tr, batches, steps):
             tr.ids.copy_(batches[i % 8], non_blocking=True)
             ev[i][0].record()
             tr._enqueue_compute()
-            tr._enqueue_update()          # rank-0-only pass: NO collective here (the other ranks are not in this loop)
+            if local_update:
+                tr._enqueue_update()      # rank-0-only pass: NO collective here (the other ranks are not in this loop)
         torch.cuda.synchronize()
     finally:
         for n in names:

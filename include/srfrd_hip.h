@@ -171,6 +171,11 @@ int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const fl
 int srfrd_reduce_dense(const float* grad_slabs, int n_slabs, int64_t n_dense, float* grad_dense,
                        const float* loss_part, int B, float* stats, float* loss_out, void* stream);
 
+/* The loss half of srfrd_reduce_dense on its own: stats[0..3] = {sum softplus(-pos), sum softplus(neg), count, 0} from the
+ * forward's loss_part (B,3); loss_out (may be NULL) = the loss of these statistics.  The data-parallel step runs it right
+ * after the forward so that the 16-byte all-reduce of the statistics overlaps the backward kernel. */
+int srfrd_loss_stats(const float* loss_part, int B, float* stats, float* loss_out, void* stream);
+
 /*
  * Optimizer state advance (one thread): t += 1, step_size = lr / (1 - b1^t), bc2_sqrt = sqrt(1 - b2^t)
  * (double precision, as torch.optim.Adam computes them on the host), next dropout seed.

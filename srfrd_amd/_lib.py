@@ -49,6 +49,7 @@ SIGNATURES = {
                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, _i64, _P, _i, _P]),
     "srfrd_aux_floats": (_i64, [_LP, _i, _i]),
     "srfrd_reduce_dense": (_i, [_P, _i, _i64, _P, _P, _i, _P, _P, _P]),
+    "srfrd_loss_stats": (_i, [_P, _i, _P, _P, _P]),
     "srfrd_step_begin": (_i, [_P, _d, _d, _d, _P]),
     "srfrd_adam_step": (_i, [_P, _P, _P, _P, _i64, _i64, _i64, _i64, _d, _d, _d, _P, _P, _P]),
     "srfrd_adam_pack_step": (_i, [_LP, _P, _P, _P, _P, _i64, _i64, _i64, _d, _d, _d, _d, _P, _P, _P, _P]),

@@ -60,6 +60,32 @@ __global__ void __launch_bounds__(256) reduce_dense_kernel(const float* __restri
   }
 }
 
+// stats[0..3] = {sum softplus(-pos), sum softplus(neg), count, 0} from the forward's per-sequence partials: the
+// data-parallel step reduces them on their own, right after the forward, so their all-reduce overlaps the backward
+__global__ void __launch_bounds__(256) loss_stats_kernel(const float* __restrict__ loss_part, int B, float* __restrict__ stats,
+                                                        float* __restrict__ loss_out) {
+  __shared__ float red[4][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    a0 += loss_part[(int64_t)b * 3 + 0];
+    a1 += loss_part[(int64_t)b * 3 + 1];
+    a2 += loss_part[(int64_t)b * 3 + 2];
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+  if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int w = 0; w < 4; ++w) s += red[w][threadIdx.x];
+    stats[threadIdx.x] = s;
+    red[0][threadIdx.x] = s;
+  }
+  if (threadIdx.x == 3) stats[3] = 0.f;
+  __syncthreads();
+  if (loss_out != nullptr && threadIdx.x == 0) loss_out[0] = red[0][0] / red[0][2] + red[0][1] / red[0][2];
+}
+
 __global__ void step_begin_kernel(uint32_t* state, double lr, double b1, double b2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) step_advance(state, lr, b1, b2);
 }
@@ -215,6 +241,12 @@ extern "C" int srfrd_reduce_dense(const float* grad_slabs, int n_slabs, int64_t 
   const int grid = (int)((n_dense + 63) / 64);
   hipLaunchKernelGGL(reduce_dense_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_slabs, n_slabs, n_dense,
                      grad_dense, loss_part, B, stats, loss_part ? loss_out : nullptr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_loss_stats(const float* loss_part, int B, float* stats, float* loss_out, void* stream) {
+  if (!loss_part || !stats || B <= 0) return SRFRD_E_ARG;
+  hipLaunchKernelGGL(loss_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_part, B, stats, loss_out);
   return (int)hipGetLastError();
 }
 

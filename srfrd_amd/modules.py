@@ -18,6 +18,9 @@ from . import _lib
 from ._lib import check, ptr
 
 
+FLAT_SLACK = 4096        # floats of zero padding kept behind a model's flat parameter vector
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -194,7 +197,9 @@ class _SRFRDBase(nn.Module):
             if all(p.data_ptr() == base + 4 * off and p.dtype == torch.float32 for p, off in slots):
                 self._slots = slots
                 return
-        flat = torch.zeros(self.n_flat, device=dev, dtype=torch.float32)
+        # (a few KiB of zeroed slack behind the vector: the data-parallel all-gather pads it to world equal shards)
+        self._flat_store = torch.zeros(self.n_flat + FLAT_SLACK, device=dev, dtype=torch.float32)
+        flat = self._flat_store[:self.n_flat]
         covered = 0
         for p, off in slots:
             n = p.numel()

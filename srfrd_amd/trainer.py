@@ -9,9 +9,13 @@ loop, all behaviour-preserving: the loss is never synchronised to the host (``lo
 and dropout masks come from the coordinate hash of csrc/srfrd_rng.h instead of torch's Bernoulli stream.
 
 Data parallel (no reference counterpart): one process per GPU, the global batch split by sequence,
-parameters replicated.  Every rank produces SUM gradients and its (loss sums, target count); one RCCL all-reduce over
-the flat [table | dense | stats] vector makes them global, and Adam divides by the GLOBAL count, so N ranks reproduce
-the single-process mean-over-all-targets loss of trainer.py:36-38 (not an average of per-rank means).
+parameters replicated, dropout masks keyed by the GLOBAL sequence index.  srfrd_amd/exchange.py holds the two forms of
+the per-step exchange; both divide by the GLOBAL count of non-pad targets, so N ranks reproduce the single-process
+mean-over-all-targets loss of trainer.py:36-38 (not an average of per-rank means):
+  "sharded" (default)  fwd -> [16-byte all-reduce of the loss statistics, overlapped with] bwd -> reduce-scatter of the
+                       flat gradient -> Adam on this rank's 1/N slice (moments exist for that slice only) -> all-gather
+                       of the stepped parameters -> re-pack of the encoder weights;
+  "allreduce"          fwd -> bwd -> one all-reduce of [gradient | statistics] -> the full fused Adam tail on every rank.
 """
 from __future__ import annotations
 
@@ -22,6 +26,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import check, ptr
+from .exchange import GradExchange, shard_bounds  # noqa: F401  (shard_bounds re-exported)
 
 
 def flat_allreduce(flat: torch.Tensor, group=None):
@@ -31,20 +36,12 @@ def flat_allreduce(flat: torch.Tensor, group=None):
     return flat
 
 
-def shard_bounds(n: int, world: int, rank: int, align: int = 4):
-    """[i0, i1) of this rank's contiguous slice of an n-element vector, i0 aligned for float4 access."""
-    per = (n + world - 1) // world
-    per = (per + align - 1) // align * align
-    i0 = min(rank * per, n)
-    return i0, min(i0 + per, n)
-
-
 class FusedTrainer:
     """Owns optimizer state and step buffers for one model on one GPU (one rank of a DP job)."""
 
     def __init__(self, model, batch_size: int, seq_len: int | None = None, lr: float = 1e-3, betas=(0.9, 0.98),
                  eps: float = 1e-8, l2_emb: float = 0.0, seed: int = 42, process_group=None, use_graph: bool = True,
-                 slots: int = 1):
+                 slots: int = 1, exchange: str = "sharded"):
         if l2_emb != 0.0:
             raise NotImplementedError("fused step supports l2_emb == 0.0 (the reference default, trainer.py:124); use the "
                                       "autograd path (model(...) + torch.optim) for a non-zero L2 term")
@@ -59,14 +56,29 @@ class FusedTrainer:
         self.n_scratch = max(n_f, n_b)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         self.n_tab, self.n_flat = model.n_table_pad, model.n_flat
+        self.ex = GradExchange(self.n_flat, process_group)
+        self.world, self.rank = self.ex.world, self.ex.rank
+        if exchange not in ("sharded", "allreduce"):
+            raise ValueError("exchange must be 'sharded' or 'allreduce'")
+        self.mode = "single" if self.world == 1 else exchange
         lay, B, L = self.lay, self.B, self.L
         f32 = dict(device=dev, dtype=torch.float32)
-        self.grad = torch.zeros(self.n_flat + 4, **f32)          # [table | dense | stats(4)]
-        self.m = torch.zeros(self.n_flat, **f32)
-        self.v = torch.zeros(self.n_flat, **f32)
+        if self.mode == "sharded":
+            # gradient padded to world equal shards; Adam moments and the reduce-scatter landing buffer for the own shard only
+            if self.ex.n_pad > model._flat_store.numel():
+                raise RuntimeError("flat parameter storage has too little slack for this world size")
+            self.flat_pad = model._flat_store[:self.ex.n_pad]
+            self.grad = torch.zeros(self.ex.n_pad, **f32)
+            self.stats = torch.zeros(4, **f32)
+            self.recv = torch.zeros(self.ex.per, **f32)
+            self.m = torch.zeros(self.ex.per, **f32)
+            self.v = torch.zeros(self.ex.per, **f32)
+        else:
+            self.grad = torch.zeros(self.n_flat + 4, **f32)      # [table | dense | stats(4)]: one vector, one all-reduce
+            self.stats = self.grad[self.n_flat:]
+            self.m = torch.zeros(self.n_flat, **f32)
+            self.v = torch.zeros(self.n_flat, **f32)
         self.state = torch.zeros(32, device=dev, dtype=torch.int32)
         self.state[1] = int(seed) & 0x7FFFFFFF
         self.n_slabs = _lib.lib().srfrd_bwd_grid(B)
@@ -89,7 +101,7 @@ class FusedTrainer:
         check(_lib.lib().srfrd_step_begin(ptr(self.state), self.lr, self.betas[0], self.betas[1],
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "srfrd_step_begin")
         self.use_graph = bool(use_graph)
-        self._graph_a = self._graph_b = None
+        self._graph_a = self._graph_b = self._graph_f = self._graph_u = None
         self.steps_done = 0
         self.err = torch.zeros(1, device=dev, dtype=torch.int32)   # srfrd_check_ids word of step() / step_packed() inputs
         self._fresh = False      # packed weights known to match the parameters (see refresh())
@@ -101,65 +113,107 @@ class FusedTrainer:
     def _dense_ptr(self, base):
         return C.c_void_p(base.data_ptr() + 4 * self.n_tab)
 
-    def _enqueue_compute(self, slot: int = 0):
-        L_, lay, st = _lib.lib(), self.lay, self._stream()
+    def _ids_of(self, slot):
         ids = self.ids_ring[slot]
         fk = ids[1] if self.lay.kind != 0 else None
         pfk, nfk = (ids[3], ids[5]) if self.lay.kind == 2 else (None, None)
         p = self.model.dropout_rate if self.model.training else 0.0
-        seed_dev = C.c_void_p(self.state.data_ptr() + 8)
-        seq0 = self.rank * self.B
+        return ids, fk, pfk, nfk, p, C.c_void_p(self.state.data_ptr() + 8), self.rank * self.B
+
+    def _enqueue_fwd(self, slot: int = 0):
+        L_, lay, st = _lib.lib(), self.lay, self._stream()
+        ids, fk, pfk, nfk, p, seed_dev, seq0 = self._ids_of(slot)
         check(L_.srfrd_encoder_fwd(C.byref(lay), ptr(self.flat), self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
                                    ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
                                    ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), ptr(self.loss_part),
                                    ptr(self.scratch), self.n_scratch, None, 0, st), "srfrd_encoder_fwd")
+        if self.mode == "sharded":       # the statistics are forward outputs: reduce them now, exchange them under the backward
+            check(L_.srfrd_loss_stats(ptr(self.loss_part), self.B, ptr(self.stats), None, st), "srfrd_loss_stats")
+
+    def _enqueue_bwd(self, slot: int = 0):
+        L_, lay, st = _lib.lib(), self.lay, self._stream()
+        ids, fk, pfk, nfk, p, seed_dev, seq0 = self._ids_of(slot)
         check(L_.srfrd_encoder_bwd(C.byref(lay), ptr(self.flat), self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
                                    ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
                                    ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), None, None, None, 1,
                                    ptr(self.grad), ptr(self.slabs), ptr(self.scratch), self.n_scratch, None, 0, st),
               "srfrd_encoder_bwd")
-        # single rank: the reduction also finalises the loss; with DP the loss needs the all-reduced stats first
+        # single rank: the slab reduction also finalises the loss; all-reduce form: it leaves the local statistics behind the
+        # gradient (one vector, one collective); sharded form: the statistics were reduced right after the forward
+        fuse_stats = self.mode != "sharded"
         check(L_.srfrd_reduce_dense(ptr(self.slabs), self.n_slabs, lay.n_dense, self._dense_ptr(self.grad),
-                                    ptr(self.loss_part), self.B, C.c_void_p(self.grad.data_ptr() + 4 * self.n_flat),
-                                    ptr(self.loss) if self.world == 1 else None, st), "srfrd_reduce_dense")
+                                    ptr(self.loss_part) if fuse_stats else None, self.B, ptr(self.stats) if fuse_stats else None,
+                                    ptr(self.loss) if self.mode == "single" else None, st), "srfrd_reduce_dense")
+
+    def _enqueue_compute(self, slot: int = 0):
+        self._enqueue_fwd(slot)
+        self._enqueue_bwd(slot)
 
     def _enqueue_update(self):
+        """single rank / all-reduce form: Adam over the whole flat vector + re-pack + optimizer-state advance, one launch"""
         L_, st = _lib.lib(), self._stream()
-        stats = C.c_void_p(self.grad.data_ptr() + 4 * self.n_flat)
-        # Adam + re-pack of the stepped weights + optimizer-state advance (t, bias corrections, seed) for the next step
         check(L_.srfrd_adam_pack_step(C.byref(self.lay), ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v),
                                       self.n_flat, self.n_tab, self.n_tab, self.lr, self.betas[0], self.betas[1], self.eps,
-                                      ptr(self.state), stats, ptr(self.packed), st), "srfrd_adam_pack_step")
+                                      ptr(self.state), ptr(self.stats), ptr(self.packed), st), "srfrd_adam_pack_step")
         if self.world > 1:
-            check(L_.srfrd_loss_finalize(stats, ptr(self.loss), st), "srfrd_loss_finalize")
+            check(L_.srfrd_loss_finalize(ptr(self.stats), ptr(self.loss), st), "srfrd_loss_finalize")
+
+    def _enqueue_shard_update(self):
+        """sharded form, between the reduce-scatter and the all-gather: re-zero the local item-table gradient (the atomics
+        of the next backward accumulate into it) and step this rank's slice; `recv`, `m`, `v` hold that slice only, so
+        their pointers are biased by -i0 to be indexed with the global element index."""
+        L_, st, ex = _lib.lib(), self._stream(), self.ex
+        self.grad[:self.n_tab].zero_()
+        bias = 4 * ex.i0
+        check(L_.srfrd_adam_step(ptr(self.flat_pad), C.c_void_p(self.recv.data_ptr() - bias), C.c_void_p(self.m.data_ptr() - bias),
+                                 C.c_void_p(self.v.data_ptr() - bias), ex.n_pad, ex.i0, ex.i1, 0, self.betas[0], self.betas[1],
+                                 self.eps, ptr(self.state), ptr(self.stats), st), "srfrd_adam_step")
+
+    def _enqueue_shard_finish(self):
+        """sharded form, after the all-gather: fragment-ordered copy of the stepped weights + optimizer-state advance + loss"""
+        L_, st = _lib.lib(), self._stream()
+        check(L_.srfrd_pack_weights(C.byref(self.lay), self._dense_ptr(self.flat), ptr(self.packed), ptr(self.state), self.lr,
+                                    self.betas[0], self.betas[1], st), "srfrd_pack_weights")
+        check(L_.srfrd_loss_finalize(ptr(self.stats), ptr(self.loss), st), "srfrd_loss_finalize")
 
     def _capture(self):
         # warm-up on a side stream (sets the LDS attributes, loads code objects), then capture
         torch.cuda.synchronize()
-        snap = (self.flat.clone(), self.m.clone(), self.v.clone(), self.state.clone(), self.grad.clone())
+        keep = [self.flat, self.m, self.v, self.state, self.grad, self.stats]
+        snap = [t.clone() for t in keep]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._enqueue_compute()
-            self._enqueue_update()
+            if self.mode == "sharded":
+                self._enqueue_shard_update()
+                self._enqueue_shard_finish()
+            else:
+                self._enqueue_update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        for dst, src in zip((self.flat, self.m, self.v, self.state, self.grad), snap):
+        for dst, src in zip(keep, snap):
             dst.copy_(src)
         self.model.pack_weights()             # the warm-up step re-packed the stepped weights: restore that too
         # thread_local capture mode: a collective backend's watchdog thread may touch the HIP runtime while we capture
-        self._graph_a = []                    # one graph per input slot (the kernels' id pointers are baked in)
-        for slot in range(self.slots):
+
+        def graph_of(fn):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self._enqueue_compute(slot)
-                if self.world == 1:
-                    self._enqueue_update()
-            self._graph_a.append(g)
-        if self.world > 1:
-            self._graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_b, capture_error_mode="thread_local"):
-                self._enqueue_update()
+                fn()
+            return g
+
+        # one graph per input slot (the kernels' id pointers are baked in)
+        if self.mode == "single":
+            self._graph_a = [graph_of(lambda k=k: (self._enqueue_compute(k), self._enqueue_update())) for k in range(self.slots)]
+        elif self.mode == "allreduce":
+            self._graph_a = [graph_of(lambda k=k: self._enqueue_compute(k)) for k in range(self.slots)]
+            self._graph_b = graph_of(self._enqueue_update)
+        else:
+            self._graph_f = [graph_of(lambda k=k: self._enqueue_fwd(k)) for k in range(self.slots)]
+            self._graph_a = [graph_of(lambda k=k: self._enqueue_bwd(k)) for k in range(self.slots)]
+            self._graph_u = graph_of(self._enqueue_shard_update)
+            self._graph_b = graph_of(self._enqueue_shard_finish)
 
     # ---- public -------------------------------------------------------------------------------
     def refresh(self):
@@ -212,17 +266,27 @@ class FusedTrainer:
     def _run(self, slot: int = 0):
         if not self._fresh:
             self.refresh()
-        if self.use_graph:
-            if self._graph_a is None:
-                self._capture()
-            self._graph_a[slot].replay()
-            if self.world > 1:
-                flat_allreduce(self.grad, self.group)
-                self._graph_b.replay()
+        g = self.use_graph
+        if g and self._graph_a is None:
+            self._capture()
+        if self.mode == "single":
+            if g:
+                self._graph_a[slot].replay()
+            else:
+                self._enqueue_compute(slot)
+                self._enqueue_update()
+        elif self.mode == "allreduce":
+            self._graph_a[slot].replay() if g else self._enqueue_compute(slot)
+            self.ex.all_reduce(self.grad)
+            self._graph_b.replay() if g else self._enqueue_update()
         else:
-            self._enqueue_compute(slot)
-            if self.world > 1:
-                flat_allreduce(self.grad, self.group)
-            self._enqueue_update()
+            self._graph_f[slot].replay() if g else self._enqueue_fwd(slot)
+            h = self.ex.all_reduce_stats(self.stats)               # 16 bytes, in flight under the backward
+            self._graph_a[slot].replay() if g else self._enqueue_bwd(slot)
+            self.ex.reduce_scatter(self.grad, self.recv)
+            h.wait()
+            self._graph_u.replay() if g else self._enqueue_shard_update()
+            self.ex.all_gather(self.flat_pad)
+            self._graph_b.replay() if g else self._enqueue_shard_finish()
         self.steps_done += 1
         return self.loss

@@ -66,8 +66,11 @@ def adam_tolerance(grad_hist, lr=1e-3, noise=5e-6, base=1e-5):
     error on an element with a real gradient; this does not.
     """
     steps = len(grad_hist)
-    gmin = torch.stack([g.detach().abs().double() for g in grad_hist]).min(0).values
-    return base + steps * lr * torch.clamp(4.0 * noise / gmin.clamp_min(1e-300), max=1.0)
+    gabs = torch.stack([g.detach().abs().double() for g in grad_hist])
+    gmin = gabs.min(0).values
+    tol = base + steps * lr * torch.clamp(4.0 * noise / gmin.clamp_min(1e-300), max=1.0)
+    # an element whose gradient is EXACTLY zero at every step (an item row no sequence touched) must not move at all
+    return torch.where(gabs.max(0).values == 0, torch.full_like(tol, 1e-7), tol)
 
 
 def assert_post_adam(msd, sd, grad_hists, D, lr=1e-3, noise=5e-6):

