@@ -245,6 +245,16 @@ int srfrd_logits_topk(const srfrd_layout* lay, const float* item_table, const fl
                       const int64_t* user_label, int k, int64_t* topk_idx, float* topk_val,
                       void* workspace, void* stream);
 
+/*
+ * Merge of per-shard top-k lists: the catalog's rows split into shards (one per GPU for the row-sharded table of BASELINE
+ * configs[4], or just to bound the ranking workspace), each ranked by srfrd_logits_topk over its [item_lo, item_hi).
+ * cand_idx int64 / cand_val (B, n_cand) hold the shards' lists side by side (n_cand = shards * k <= 4096; idx < 0 marks an
+ * empty slot); topk_idx / topk_val (B, k) receive the k best in stable descending order (value desc, item id asc): what
+ * ONE srfrd_logits_topk over the whole catalog returns, ties across shard boundaries included.
+ */
+int srfrd_topk_merge(const int64_t* cand_idx, const float* cand_val, int B, int n_cand, int k,
+                     int64_t* topk_idx, float* topk_val, void* stream);
+
 /* HR@10 / NDCG@10 inputs (reference utils.py:589-597): rank[b] = #{i >= 1 : logits[b][i] > logits[b][0]};
  * metric_acc[0] += [rank<10] / log2(rank+2), metric_acc[1] += [rank<10], metric_acc[2] += 1 (double[3]). */
 int srfrd_eval_rank(const float* logits, int B, int n_cand, int32_t* rank, double* metric_acc, void* stream);

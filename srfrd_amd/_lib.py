@@ -59,6 +59,7 @@ SIGNATURES = {
     "srfrd_predict_logits": (_i, [_LP, _P, _P, _P, _i, _i, _P, _i, _i64, _P, _P, _P]),
     "srfrd_topk_workspace_bytes": (_i64, [_i, _i, _i64]),
     "srfrd_logits_topk": (_i, [_LP, _P, _P, _P, _i, _i, _i64, _i64, _i, _P, _i, _P, _P, _P, _P]),
+    "srfrd_topk_merge": (_i, [_P, _P, _i, _i, _i, _P, _P, _P]),
     "srfrd_eval_rank": (_i, [_P, _i, _i, _P, _P, _P]),
     "srfrd_sample_batch": (_i, [_P, _P, _P, _i, _i, _i, _i, _u32, _u32, _P, _P, _P]),
 }

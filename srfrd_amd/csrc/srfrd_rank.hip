@@ -1,5 +1,7 @@
 // Ranking-side kernels: user labels, candidate logits (predict), full-catalog top-k, HR@10 / NDCG@10 ranks.
 // Reference: SRFR_model.py:144-152 (+ :241-259, :532-540, :668-681), :546-570; utils.py:576-598.
+#include <mutex>
+
 #include "srfrd_dev.h"
 
 namespace srfrd {
@@ -456,6 +458,49 @@ __global__ void __launch_bounds__(256) topk_stage2_kernel(const Cand* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// merge of per-shard top-k lists (row-sharded catalog, BASELINE configs[4]): per user n_cand = shards x k candidates
+// (idx < 0 = empty slot) -> the k best in stable descending order (value desc, item id asc) - the order one unsharded
+// ranking returns, ties across shard boundaries included.  One wave per user, k rounds of (argmax, remove).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) topk_merge_kernel(const int64_t* __restrict__ cand_idx, const float* __restrict__ cand_val,
+                                                        int B, int n_cand, int k, int64_t* __restrict__ out_idx,
+                                                        float* __restrict__ out_val) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (b >= B) return;
+  float* sv = smem + (size_t)wave * 2 * n_cand;
+  int* si = (int*)(sv + n_cand);
+  for (int j = lane; j < n_cand; j += 64) {
+    const int64_t id = cand_idx[(int64_t)b * n_cand + j];
+    sv[j] = cand_val[(int64_t)b * n_cand + j];
+    si[j] = id < 0 ? -1 : (int)id;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int r = 0; r < k; ++r) {
+    float bv = -INFINITY;
+    int bi = 0x7FFFFFFF, bp = -1;
+    for (int j = lane; j < n_cand; j += 64) {
+      const int id = si[j];
+      if (id >= 0 && (bp < 0 || better(sv[j], id, bv, bi))) { bv = sv[j]; bi = id; bp = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      const int op = __shfl_xor(bp, o, 64);
+      if (op >= 0 && (bp < 0 || better(ov, oi, bv, bi))) { bv = ov; bi = oi; bp = op; }
+    }
+    if (lane == 0) {
+      out_idx[(int64_t)b * k + r] = bp >= 0 ? bi : -1;
+      out_val[(int64_t)b * k + r] = bp >= 0 ? bv : -INFINITY;
+      if (bp >= 0) si[bp] = -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // rank of candidate 0 (strictly-greater count) + HR@10 / NDCG@10 accumulation (fp64, as the host loop does)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) eval_rank_kernel(const float* __restrict__ logits, int B, int n_cand,
@@ -543,7 +588,12 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const float* item_tabl
   const size_t lds = ((size_t)kChunk * DSi + 16 * DSi + 16 * (kChunk + 2) + 16 + kSlack) * sizeof(float);
   if (lds > (size_t)kLdsLimit) return SRFRD_E_UNSUPPORTED;
   const size_t lds_stream = ((size_t)kChunk * DSi + 2 * 16 * DSi + 32 + 8 * 16 + kSlack) * sizeof(float);   // topk_stream
-  static size_t s_attr = 0;
+  static std::mutex attr_mu;
+  static size_t attr_dev[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SRFRD_E_DEVICE;
+  std::lock_guard<std::mutex> attr_lock(attr_mu);
+  size_t& s_attr = attr_dev[dev];
   if (lds > s_attr) {
     if (hipFuncSetAttribute((const void*)topk_stage1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)topk_max_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stream) != hipSuccess ||
@@ -585,6 +635,27 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const float* item_tabl
                      item_hi, exclude_pad, user_label, k, n_chunks, fb, (const int32_t*)(a.ccnt + B));
   hipLaunchKernelGGL(topk_stage2_kernel, dim3((B + 3) / 4), dim3(256), 0, st, (const Cand*)fb, B, k, n_chunks, topk_idx,
                      topk_val, (const int32_t*)(a.ccnt + B));
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_topk_merge(const int64_t* cand_idx, const float* cand_val, int B, int n_cand, int k, int64_t* topk_idx,
+                                float* topk_val, void* stream) {
+  if (!cand_idx || !cand_val || !topk_idx || !topk_val || B <= 0 || n_cand <= 0 || k <= 0 || n_cand > 4096) return SRFRD_E_ARG;
+  const size_t lds = (size_t)4 * 2 * n_cand * sizeof(float);       // 4 waves per block, (value, id) per candidate: <= 128 KiB
+  static std::mutex mu;
+  static size_t opted[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SRFRD_E_DEVICE;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (lds > 48 * 1024 && lds > opted[dev]) {
+      if (hipFuncSetAttribute((const void*)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SRFRD_E_DEVICE;
+      opted[dev] = lds;
+    }
+  }
+  hipLaunchKernelGGL(topk_merge_kernel, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, cand_idx, cand_val, B, n_cand, k,
+                     topk_idx, topk_val);
   return (int)hipGetLastError();
 }
 
