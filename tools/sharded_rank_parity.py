@@ -42,7 +42,7 @@ def main():
             torch.nn.init.xavier_normal_(p.data)
     with torch.no_grad():
         w = m._item_param()
-        w[[10000, 10006, 19000]] = w[5]                      # exact ties across the shard boundary
+        w[[10000, 10006, 19000]] = w[5].clone()              # exact ties across the shard boundary
     m = m.to(dev).eval()
     _, seq, rsq, *_ = srfrd_amd.synthetic_batch(I, L, B, seed=3, rank=rank, device=dev)
     r = srfrd_amd.ShardedRanker(m)
