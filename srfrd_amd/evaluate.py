@@ -11,7 +11,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, ops  # noqa: F401  (ops: registers torch.ops.srfrd.*)
 from ._lib import check, ptr
 
 
@@ -19,6 +19,8 @@ def ranks_from_logits(logits: torch.Tensor, metric_acc: torch.Tensor | None = No
     """rank of candidate 0 per row of (B, n_cand) logits; optionally accumulates [ndcg_sum, hit_sum, users] (fp64)."""
     if logits.device.type != "cuda":
         raise RuntimeError("ranks_from_logits runs on the ROCm GPU only")
+    if metric_acc is None:
+        return torch.ops.srfrd.eval_rank(logits)
     logits = logits.contiguous()
     B, n = logits.shape
     rank = torch.empty(B, device=logits.device, dtype=torch.int32)

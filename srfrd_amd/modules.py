@@ -14,7 +14,7 @@ import ctypes as C
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check, ptr
 
 
@@ -77,35 +77,6 @@ class SRFU_Embedding(nn.Module):
 
     def get_user_label_embed(self):
         return self.user_label_embed
-
-
-class _EncoderFn(torch.autograd.Function):
-    """autograd bridge: forward = srfrd_encoder_fwd, backward = srfrd_encoder_bwd + srfrd_reduce_dense."""
-
-    @staticmethod
-    def forward(ctx, model, ids, dropout_p, seed, *params):
-        inp, fk, pos, pfk, neg, nfk = ids
-        out = model._launch_fwd(inp, fk, pos, pfk, neg, nfk, dropout_p, seed, save=True)
-        ctx.model, ctx.ids, ctx.dropout_p, ctx.seed = model, ids, dropout_p, seed
-        ctx.saved = out
-        hidden, pl, nl = out["hidden"], out["pos_logits"], out["neg_logits"]
-        empty = hidden.new_empty(0)
-        return hidden, (pl if pl is not None else empty), (nl if nl is not None else empty)
-
-    @staticmethod
-    def backward(ctx, d_hidden, d_pl, d_nl):
-        model, out = ctx.model, ctx.saved
-        inp, fk, pos, pfk, neg, nfk = ctx.ids
-        if out["pos_logits"] is None:
-            d_pl = None
-        if out["neg_logits"] is None:
-            d_nl = None
-        gflat = model._launch_bwd(inp, fk, pos, pfk, neg, nfk, ctx.dropout_p, ctx.seed, out,
-                                  None if d_hidden is None else d_hidden.contiguous(),
-                                  None if d_pl is None else d_pl.contiguous(),
-                                  None if d_nl is None else d_nl.contiguous())
-        grads = tuple(gflat[off:off + p.numel()].view(p.shape) for p, off in model._slots)
-        return (None, None, None, None) + grads
 
 
 class _SRFRDBase(nn.Module):
@@ -322,21 +293,18 @@ class _SRFRDBase(nn.Module):
         ids = self._prep(input_ids, fake_ids, positive_ids, positive_fake_ids, negative_ids, negative_fake_ids)
         p = self.dropout_rate if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
-        if torch.is_grad_enabled() and any(q.requires_grad for q, _ in self._slots):
-            hidden, pl, nl = _EncoderFn.apply(self, ids, p, seed, *[q for q, _ in self._slots])
-            return hidden, (pl if ids[2] is not None else None), (nl if ids[4] is not None else None)
-        out = self._launch_fwd(*ids, p, seed, save=False)
-        return out["hidden"], out["pos_logits"], out["neg_logits"]
+        # torch.ops.srfrd.encoder_fwd (srfrd_amd/ops.py): the parameters are op inputs, its registered backward runs
+        # srfrd::encoder_bwd and hands one gradient per parameter to autograd
+        grad = torch.is_grad_enabled() and any(q.requires_grad for q, _ in self._slots)
+        hidden, pl, nl, *_ = torch.ops.srfrd.encoder_fwd([q for q, _ in self._slots], *ids, ops.register_model(self), p, seed, 0, grad)
+        return hidden, (pl if ids[2] is not None else None), (nl if ids[4] is not None else None)
 
     def user_labels(self, fake_ids):
         """get_Labels (SRFU_*) / the predict-time label (SRFRN) as an int64 (B,) tensor, computed on device."""
         self._ensure_flat()
         fk = _ids(fake_ids, self._flat.device)
-        lab = torch.empty(fk.shape[0], device=fk.device, dtype=torch.int64)
         kind = _lib.KINDS[self._kind] if self._kind != "SRFR" else _lib.KINDS["SRFRN"]
-        check(_lib.lib().srfrd_user_labels(kind, ptr(fk), fk.shape[0], fk.shape[1], ptr(lab), _stream()),
-              "srfrd_user_labels")
-        return lab
+        return torch.ops.srfrd.user_labels(fk, kind)
 
     def predict(self, user_ids, input_ids, fake_ids, label):
         """reference predict(): logits of the candidate items ``label`` against the last position's state.
@@ -363,11 +331,7 @@ class _SRFRDBase(nn.Module):
                                              ptr(self._err_word(dev)), _stream()), "srfrd_check_ids")
             if self.validate_ids == "eager":
                 self.check_ids()
-        logits = torch.empty(B, n_cand, device=dev, dtype=torch.float32)
-        check(_lib.lib().srfrd_predict_logits(
-            C.byref(lay), ptr(self._flat), C.c_void_p(self._flat.data_ptr() + 4 * self.n_table_pad), ptr(hidden), B, L,
-            ptr(cand), n_cand, stride, ptr(ulab), ptr(logits), _stream()), "srfrd_predict_logits")
-        return logits
+        return torch.ops.srfrd.predict_logits(hidden.contiguous(), cand.contiguous(), ulab, ops.register_model(self))
 
     def topk(self, user_ids, input_ids, fake_ids, k=10, exclude_pad=True, item_range=None):
         """Full-catalog ranking: (indices int64 (B,k), scores (B,k)); the (B, I) logits never reach HBM."""
@@ -379,12 +343,7 @@ class _SRFRDBase(nn.Module):
         B, L = hidden.shape[0], hidden.shape[1]
         lo, hi = item_range if item_range is not None else (0, lay.n_items + 1)
         ulab = self.user_labels(ids[1]) if self._kind == "SRFRN" else None
-        ws = torch.empty(max(_lib.lib().srfrd_topk_workspace_bytes(B, k, hi - lo), 8), device=hidden.device, dtype=torch.uint8)
-        idx = torch.empty(B, k, device=hidden.device, dtype=torch.int64)
-        val = torch.empty(B, k, device=hidden.device, dtype=torch.float32)
-        check(_lib.lib().srfrd_logits_topk(
-            C.byref(lay), ptr(self._flat), C.c_void_p(self._flat.data_ptr() + 4 * self.n_table_pad), ptr(hidden), B, L,
-            lo, hi, 1 if exclude_pad else 0, ptr(ulab), k, ptr(idx), ptr(val), ptr(ws), _stream()), "srfrd_logits_topk")
+        idx, val = torch.ops.srfrd.logits_topk(hidden, ulab, ops.register_model(self), lo, hi, k, bool(exclude_pad))
         return idx, val
 
 

@@ -38,15 +38,10 @@ def row_shards(n_rows: int, n_shards: int):
 
 
 def topk_merge(cand_idx: torch.Tensor, cand_val: torch.Tensor, k: int):
-    """(B, n_cand) candidate lists -> (idx int64 (B,k), val (B,k)) in stable descending order (srfrd_topk_merge)."""
+    """(B, n_cand) candidate lists -> (idx int64 (B,k), val (B,k)) in stable descending order (srfrd::topk_merge)."""
     if cand_idx.device.type != "cuda":
         raise RuntimeError("topk_merge runs on the ROCm GPU only")
-    cand_idx, cand_val = cand_idx.contiguous(), cand_val.contiguous()
-    B, n = cand_idx.shape
-    idx = torch.empty(B, k, device=cand_idx.device, dtype=torch.int64)
-    val = torch.empty(B, k, device=cand_idx.device, dtype=torch.float32)
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    check(_lib.lib().srfrd_topk_merge(ptr(cand_idx), ptr(cand_val), B, n, k, ptr(idx), ptr(val), st), "srfrd_topk_merge")
+    idx, val = torch.ops.srfrd.topk_merge(cand_idx, cand_val, k)
     return idx, val
 
 
@@ -62,17 +57,8 @@ class ShardedRanker:
         self.shards = row_shards(model.layout.n_items + 1, self.n_shards)
 
     def _rank_shard(self, h_last, ulab, lo, hi, k, exclude_pad):
-        m = self.model
-        lay, flat = m.layout, m._flat
-        U = h_last.shape[0]
-        dev = h_last.device
-        ws = torch.empty(max(_lib.lib().srfrd_topk_workspace_bytes(U, k, hi - lo), 8), device=dev, dtype=torch.uint8)
-        idx = torch.empty(U, k, device=dev, dtype=torch.int64)
-        val = torch.empty(U, k, device=dev, dtype=torch.float32)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(_lib.lib().srfrd_logits_topk(C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * m.n_table_pad), ptr(h_last), U, 1,
-                                           lo, hi, 1 if exclude_pad else 0, ptr(ulab), k, ptr(idx), ptr(val), ptr(ws), st),
-              "srfrd_logits_topk")
+        from . import ops
+        idx, val = torch.ops.srfrd.logits_topk(h_last.unsqueeze(1), ulab, ops.register_model(self.model), lo, hi, k, bool(exclude_pad))
         return idx, val
 
     @torch.no_grad()

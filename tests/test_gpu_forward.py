@@ -211,3 +211,28 @@ def test_out_of_range_ids_are_clamped_and_reported():
     with pytest.raises(IndexError, match="item ids up to 70"):
         srfrd_amd.DeviceSampler(d, 4, 20, model=tr)
     srfrd_amd.DeviceSampler(d, 4, 20)                               # unwired: no model to check against
+
+
+def test_custom_ops_pass_opcheck_and_carry_autograd():
+    """torch.library.opcheck on the registered ops: schema, fake-tensor (meta) implementation and autograd registration
+    of srfrd::encoder_fwd against its real CUDA implementation."""
+    import srfrd_amd
+    from srfrd_amd import ops
+    from tests.gpu_util import build_model, random_sd
+    cfg = O.Cfg("SRFRN", 90, 20, 45, d_fake=5)
+    model = build_model(cfg, random_sd(cfg, seed=4)).train()
+    model.dropout_rate = 0.0
+    _, seq, rsq, pos, prs, neg, nrs = srfrd_amd.synthetic_batch(90, 20, 6, seed=2, device="cuda")
+    ids = model._prep(seq, rsq, pos, prs, neg, nrs)
+    key = ops.register_model(model)
+    params = [q for q, _ in model._slots]
+    args = (params, *ids, key, 0.0, 0, 0, True)
+    torch.library.opcheck(torch.ops.srfrd.encoder_fwd.default, args, test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    out = torch.ops.srfrd.encoder_fwd(*args)
+    assert out[0].requires_grad and out[1].grad_fn is not None
+    torch.library.opcheck(torch.ops.srfrd.user_labels.default, (rsq, 2), test_utils=("test_schema", "test_faketensor"))
+    h = out[0].detach()
+    torch.library.opcheck(torch.ops.srfrd.logits_topk.default, (h, model.user_labels(rsq), key, 0, 91, 5, True),
+                          test_utils=("test_schema", "test_faketensor"))
+    cand = torch.randint(1, 91, (6, 11), device="cuda")
+    torch.library.opcheck(torch.ops.srfrd.predict_logits.default, (h, cand, model.user_labels(rsq), key), test_utils=("test_schema", "test_faketensor"))
