@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="exploration only; the contract line is C2")
+    ap.add_argument("--deterministic", action="store_true", help="deterministic item-table scatter (sort + ordered sums) instead of float atomics")
     ap.add_argument("--predict", action="store_true", help="time forward + full-catalog top-10 instead of the train step")
     args = ap.parse_args()
 
@@ -179,7 +180,7 @@ def main():
     # "inputs already in HBM"): each step consumes one slot in place, as it would a slot a device sampler just filled
     ring = 1 if os.environ.get("SRFRD_BENCH_COPY") else 8
     tr = srfrd_amd.FusedTrainer(model, B, L, lr=1e-3, betas=(0.9, 0.98), seed=42, use_graph=not args.no_graph, slots=ring,
-                                exchange=os.environ.get("SRFRD_DP_EXCHANGE", "sharded"))
+                                exchange=os.environ.get("SRFRD_DP_EXCHANGE", "sharded"), deterministic=args.deterministic)
     batches = [srfrd_amd.synthetic_batch(cfg["n_items"], L, B, seed=1, index=i, rank=rank, device=dev, packed=True)[1]
                for i in range(8)]
     if ring == 8:
@@ -233,7 +234,8 @@ def main():
             "config": {"workload": "C2: SASRec train step (fwd + masked BCE + bwd + dense Adam), 50k items, seq_len 50, "
                                    "batch 512 per GPU, hidden 50, 2 blocks, 1 head, dropout 0.5",
                        "global_batch": world * B, "seq_len": L, "n_items": cfg["n_items"],
-                       "parallelism": f"dp{world}", "exchange": tr.mode, "graph": not args.no_graph, "final_loss": loss},
+                       "parallelism": f"dp{world}", "exchange": tr.mode, "graph": not args.no_graph, "table_scatter": "sort + ordered sums" if args.deterministic else "float atomics",
+                       "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
                          "avg_kernel_ms": kt[dom], "algorithmic_flops_per_launch": dom_flops,

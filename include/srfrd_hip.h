@@ -151,6 +151,9 @@ int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const fl
  *    (SUM reduction: the 1/count of the two means is applied by srfrd_adam_step via `stats`), d_hidden = 0;
  *  fused_bce == 0: upstream gradients d_hidden (B,L,d_out) / d_pos / d_neg (B,L) are read (each may be NULL).
  *  grad_table (n_items+1, d_item): += by float atomics (caller zeroes it; row 0 never written: padding_idx)
+ *  table_contrib: NULL, or (3, B, L, d_item) floats for the DETERMINISTIC item-table scatter: instead of the atomics every
+ *    (target kind {pos, neg, input}, sequence, position) writes its row contribution here (zeros where it has none) and
+ *    srfrd_table_reduce sums the rows of each item in a fixed order into grad_table (bitwise reproducible)
  *  grad_slabs (srfrd_bwd_grid(B), n_dense): per-workgroup partial dense gradients (fully overwritten)
  */
 int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
@@ -161,9 +164,20 @@ int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const fl
                       const float* hidden, const float* pos_logits, const float* neg_logits,
                       const float* save_x, const float* save_h1, const float* save_aux,
                       const float* d_hidden, const float* d_pos, const float* d_neg, int fused_bce,
-                      float* grad_table, float* grad_slabs,
+                      float* grad_table, float* table_contrib, float* grad_slabs,
                       float* scratch, int64_t scratch_floats,
                       float* dbg, int dbg_seq, void* stream);
+
+/*
+ * Deterministic item-table scatter, second half (the first is srfrd_encoder_bwd with table_contrib): n = 3 * B * L keys
+ * (the item id each contribution row belongs to: pos ids, neg ids, input ids, in table_contrib's row order) sorted
+ * ascending by a STABLE sort, with `order[i]` = the contribution row that sorted position i came from.  One wave per
+ * run of equal keys adds that item's rows in sorted order and stores the sum to grad_table[key] (key 0 = padding_idx is
+ * skipped; rows without contributions are not touched: the caller keeps them zero).  The summation order is a function
+ * of the ids alone => the table gradient is bitwise reproducible, unlike the float-atomic form.
+ */
+int srfrd_table_reduce(const int64_t* sorted_keys, const int64_t* order, const float* table_contrib, int64_t n, int d_item,
+                       float* grad_table, void* stream);
 
 /* Sums the per-workgroup slabs into grad_dense (n_dense) in a fixed order (bitwise reproducible) and, if
  * loss_part != NULL, reduces it into stats[0..3] = {sum softplus(-pos), sum softplus(neg), count, 0}; with loss_out != NULL

@@ -46,7 +46,8 @@ SIGNATURES = {
     "srfrd_encoder_fwd": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
                                _P, _P, _P, _P, _P, _P, _P, _P, _i64, _P, _i, _P]),
     "srfrd_encoder_bwd": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
-                               _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, _i64, _P, _i, _P]),
+                               _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, _P, _i64, _P, _i, _P]),
+    "srfrd_table_reduce": (_i, [_P, _P, _P, _i64, _i, _P, _P]),
     "srfrd_aux_floats": (_i64, [_LP, _i, _i]),
     "srfrd_reduce_dense": (_i, [_P, _i, _i64, _P, _P, _i, _P, _P, _P]),
     "srfrd_loss_stats": (_i, [_P, _i, _P, _P, _P]),

@@ -27,8 +27,8 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_tabl
                                  const float* hidden, const float* pos_logits, const float* neg_logits,
                                  const float* save_x, const float* save_h1, const float* save_aux, const float* d_hidden,
                                  const float* d_pos,
-                                 const float* d_neg, int fused_bce, float* grad_table, float* grad_slabs, float* scratch,
-                                 int64_t scratch_floats, float* dbg, int dbg_seq, void* stream) {
+                                 const float* d_neg, int fused_bce, float* grad_table, float* table_contrib, float* grad_slabs,
+                                 float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq, void* stream) {
   EncArgs a = {};
   int rc = fill_args(a, lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
                      dropout_p, seed, seed_dev, seq_index0);
@@ -37,7 +37,7 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_tabl
   if (fused_bce && !(pos_ids && neg_ids && pos_logits && neg_logits)) return SRFRD_E_ARG;
   a.c_hidden = hidden; a.c_pl = pos_logits; a.c_nl = neg_logits; a.c_save_x = save_x; a.c_save_h1 = save_h1; a.c_save_aux = save_aux;
   a.d_hidden = d_hidden; a.d_pos = d_pos; a.d_neg = d_neg; a.fused_bce = fused_bce;
-  a.grad_table = grad_table; a.grad_slabs = grad_slabs;
+  a.grad_table = grad_table; a.grad_slabs = grad_slabs; a.contrib = table_contrib;
   a.dbg = dbg; a.dbg_seq = dbg_seq;
   srfrd_debug_shape(lay, L, &a.dbg_slot, nullptr);
   const Geom g = make_geom(L, lay->D);

@@ -86,6 +86,21 @@ __global__ void __launch_bounds__(256) loss_stats_kernel(const float* __restrict
   if (loss_out != nullptr && threadIdx.x == 0) loss_out[0] = red[0][0] / red[0][2] + red[0][1] / red[0][2];
 }
 
+// deterministic item-table scatter: one wave per sorted position; the wave at the head of a run of equal keys owns the item
+__global__ void __launch_bounds__(256) table_reduce_kernel(const int64_t* __restrict__ keys, const int64_t* __restrict__ order,
+                                                          const float* __restrict__ contrib, int64_t n, int di,
+                                                          float* __restrict__ grad_table) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int64_t key = keys[i];
+  if (key == 0 || (i > 0 && keys[i - 1] == key)) return;          // padding_idx row, or not the head of its run
+  float acc = 0.f;
+  for (int64_t j = i; j < n && keys[j] == key; ++j)
+    if (lane < di) acc += contrib[order[j] * di + lane];
+  if (lane < di) grad_table[key * di + lane] = acc;
+}
+
 __global__ void step_begin_kernel(uint32_t* state, double lr, double b1, double b2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) step_advance(state, lr, b1, b2);
 }
@@ -241,6 +256,14 @@ extern "C" int srfrd_reduce_dense(const float* grad_slabs, int n_slabs, int64_t 
   const int grid = (int)((n_dense + 63) / 64);
   hipLaunchKernelGGL(reduce_dense_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, grad_slabs, n_slabs, n_dense,
                      grad_dense, loss_part, B, stats, loss_part ? loss_out : nullptr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_table_reduce(const int64_t* sorted_keys, const int64_t* order, const float* table_contrib, int64_t n, int d_item,
+                                  float* grad_table, void* stream) {
+  if (!sorted_keys || !order || !table_contrib || !grad_table || n <= 0 || d_item <= 0 || d_item > 64) return SRFRD_E_ARG;
+  hipLaunchKernelGGL(table_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sorted_keys, order,
+                     table_contrib, n, d_item, grad_table);
   return (int)hipGetLastError();
 }
 

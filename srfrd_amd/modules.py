@@ -232,7 +232,7 @@ class _SRFRDBase(nn.Module):
             C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(self._packed),
             ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
             None, int(seq0), ptr(out["hidden"]), ptr(out["pos_logits"]), ptr(out["neg_logits"]), ptr(out["save_x"]),
-            ptr(out["save_h1"]), ptr(out["save_aux"]), ptr(d_hidden), ptr(d_pl), ptr(d_nl), 0, ptr(gflat), ptr(slabs), ptr(scratch), n_scr,
+            ptr(out["save_h1"]), ptr(out["save_aux"]), ptr(d_hidden), ptr(d_pl), ptr(d_nl), 0, ptr(gflat), None, ptr(slabs), ptr(scratch), n_scr,
             ptr(dbg), int(dbg_seq), _stream()), "srfrd_encoder_bwd")
         check(_lib.lib().srfrd_reduce_dense(ptr(slabs), n_slabs, lay.n_dense,
                                             C.c_void_p(gflat.data_ptr() + 4 * self.n_table_pad), None, B, None, None,

@@ -41,7 +41,10 @@ class FusedTrainer:
 
     def __init__(self, model, batch_size: int, seq_len: int | None = None, lr: float = 1e-3, betas=(0.9, 0.98),
                  eps: float = 1e-8, l2_emb: float = 0.0, seed: int = 42, process_group=None, use_graph: bool = True,
-                 slots: int = 1, exchange: str = "sharded"):
+                 slots: int = 1, exchange: str = "sharded", deterministic: bool = False):
+        """``deterministic``: the item-table gradient is scattered by a stable sort + per-item ordered sums instead of float
+        atomics - every step bitwise reproducible (the dense gradients already are: fixed slab tree), at the cost of one
+        sort of 3 B L keys per step."""
         if l2_emb != 0.0:
             raise NotImplementedError("fused step supports l2_emb == 0.0 (the reference default, trainer.py:124); use the "
                                       "autograd path (model(...) + torch.optim) for a non-zero L2 term")
@@ -81,6 +84,9 @@ class FusedTrainer:
             self.v = torch.zeros(self.n_flat, **f32)
         self.state = torch.zeros(32, device=dev, dtype=torch.int32)
         self.state[1] = int(seed) & 0x7FFFFFFF
+        self.deterministic = bool(deterministic)
+        self.contrib = torch.zeros(3, B, L, lay.d_item, **f32) if self.deterministic else None
+        self.keys = torch.zeros(3, B, L, device=dev, dtype=torch.int64) if self.deterministic else None
         self.n_slabs = _lib.lib().srfrd_bwd_grid(B)
         self.slabs = torch.empty(self.n_slabs, lay.n_dense, **f32)
         # Input ring: `slots` resident (6, B, L) id buffers.  A producer (DeviceSampler, a loader thread's H2D copy)
@@ -136,8 +142,15 @@ class FusedTrainer:
         check(L_.srfrd_encoder_bwd(C.byref(lay), ptr(self.flat), self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
                                    ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
                                    ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), None, None, None, 1,
-                                   ptr(self.grad), ptr(self.slabs), ptr(self.scratch), self.n_scratch, None, 0, st),
+                                   ptr(self.grad), ptr(self.contrib), ptr(self.slabs), ptr(self.scratch), self.n_scratch, None, 0, st),
               "srfrd_encoder_bwd")
+        if self.contrib is not None:
+            # deterministic item-table scatter: stable sort of the 3 B L row keys (pos, neg, input ids - the row order of
+            # `contrib`), then one wave per item adds its rows in that order
+            torch.stack((ids[2], ids[4], ids[0]), out=self.keys)
+            skeys, order = torch.sort(self.keys.view(-1), stable=True)
+            check(L_.srfrd_table_reduce(ptr(skeys), ptr(order), ptr(self.contrib), skeys.numel(), lay.d_item, ptr(self.grad), st),
+                  "srfrd_table_reduce")
         # single rank: the slab reduction also finalises the loss; all-reduce form: it leaves the local statistics behind the
         # gradient (one vector, one collective); sharded form: the statistics were reduced right after the forward
         fuse_stats = self.mode != "sharded"
