@@ -59,8 +59,9 @@ def encoder_fwd(params: List[torch.Tensor], input_ids: torch.Tensor, fake_ids: O
     """-> [hidden, pos_logits, neg_logits, save_x, save_h1, save_aux] (absent outputs are empty tensors)."""
     m = _model(model_key)
     out = m._launch_fwd(input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, dropout_p, seed, save, seq0=seq0)
-    e = out["hidden"].new_empty(0)
-    return [out["hidden"]] + [out[k] if out[k] is not None else e for k in ("pos_logits", "neg_logits", "save_x", "save_h1", "save_aux")]
+    # (a fresh empty tensor per absent output: custom-op returns may not alias one another)
+    return [out["hidden"]] + [out[k] if out[k] is not None else out["hidden"].new_empty(0)
+                              for k in ("pos_logits", "neg_logits", "save_x", "save_h1", "save_aux")]
 
 
 @encoder_fwd.register_fake
@@ -69,12 +70,11 @@ def _(params, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, model_k
     lay = m.layout
     B, L = input_ids.shape
     f = dict(device=input_ids.device, dtype=torch.float32)
-    e = torch.empty(0, **f)
-    return [torch.empty(B, L, lay.d_out, **f), torch.empty(B, L, **f) if pos_ids is not None else e,
-            torch.empty(B, L, **f) if neg_ids is not None else e,
-            torch.empty(lay.n_blocks + 1, B, L, lay.D, **f) if save else e,
-            torch.empty(lay.n_blocks, B, L, lay.D, **f) if save else e,
-            torch.empty(_lib.lib().srfrd_aux_floats(C.byref(lay), B, L), **f) if save else e]
+    return [torch.empty(B, L, lay.d_out, **f), torch.empty(B, L, **f) if pos_ids is not None else torch.empty(0, **f),
+            torch.empty(B, L, **f) if neg_ids is not None else torch.empty(0, **f),
+            torch.empty(lay.n_blocks + 1, B, L, lay.D, **f) if save else torch.empty(0, **f),
+            torch.empty(lay.n_blocks, B, L, lay.D, **f) if save else torch.empty(0, **f),
+            torch.empty(_lib.lib().srfrd_aux_floats(C.byref(lay), B, L), **f) if save else torch.empty(0, **f)]
 
 
 # ------------------------------------------------------------------------------------------------ encoder backward

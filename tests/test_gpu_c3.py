@@ -1,0 +1,111 @@
+"""-m gpu: BASELINE.json configs[2] (C3) at FULL size - 50 000 items, seq_len 50, batch 512, the "userDiscriminator joint"
+stand-ins SRFRN ([item || fake] channel, targets carry their fake embedding) and SRFU_B (user-label channel).  The CPU
+oracle cannot run this size in seconds, so the same size-independent properties C2 is held to (tests/test_gpu_ranking.py)
+are checked: bitwise repeatability, batch-slot invariance, causality, exact linearity of the backward in the upstream
+gradient, untouched table rows exactly zero, fused step == autograd + torch.optim.Adam step, chance-level HR@10 untrained."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+I, L, B = 50_000, 50, 512
+
+
+@pytest.fixture(scope="module", params=["SRFRN", "SRFU_B"])
+def c3(request):
+    import srfrd_amd
+    torch.manual_seed(0)
+    if request.param == "SRFRN":
+        m = srfrd_amd.SRFRN(I, L, 45, 5, 0.5, 2, 1, "cuda")
+    else:
+        m = srfrd_amd.SRFU_B(I, L, 50, 3, 0.5, 2, 1, "cuda")
+    for _, p in m.named_parameters():
+        if p.dim() >= 2:
+            torch.nn.init.xavier_normal_(p.data)
+    m = m.cuda()
+    return request.param, m, srfrd_amd.synthetic_batch(I, L, B, seed=1, device="cuda")
+
+
+def test_c3_forward_deterministic_causal_and_batch_invariant(c3):
+    kind, m, (u, seq, rsq, pos, prs, neg, nrs) = c3
+    m.eval()
+    with torch.no_grad():
+        h1, p1, n1 = m(u, seq, rsq, pos, prs, neg, nrs)
+        h2, p2, n2 = m(u, seq, rsq, pos, prs, neg, nrs)
+        assert torch.equal(h1, h2) and torch.equal(p1, p2) and torch.equal(n1, n2)
+        perm = torch.randperm(B, device="cuda")[:100]
+        h3, p3, n3 = m(u, seq[perm], rsq[perm], pos[perm], prs[perm], neg[perm], nrs[perm])
+        assert torch.equal(h3, h1[perm]) and torch.equal(p3, p1[perm]) and torch.equal(n3, n1[perm])
+        seq2 = seq.clone()
+        seq2[:, -1] = (seq2[:, -1] % (I - 1)) + 1
+        h4, _, _ = m(u, seq2, rsq, pos, prs, neg, nrs)
+        assert torch.equal(h4[:, :-1], h1[:, :-1]) and not torch.equal(h4[:, -1], h1[:, -1])
+        assert bool(torch.isfinite(h1).all())
+        if kind == "SRFU_B":            # the user label reads the whole window: flipping one review id can move every position
+            rsq2 = rsq.clone()
+            rsq2[:, -1] = 3 - rsq2[:, -1].clamp(min=1)
+            lab1, lab2 = m.get_Labels(rsq), m.get_Labels(rsq2)
+            h5, _, _ = m(u, seq, rsq2, pos, prs, neg, nrs)
+            same = lab1 == lab2
+            assert torch.equal(h5[same], h1[same]) and bool((lab1 != lab2).any())
+
+
+def test_c3_gradients_are_linear_in_the_upstream_gradient(c3):
+    kind, m, (u, seq, rsq, pos, prs, neg, nrs) = c3
+    m.eval()
+    ids = m._prep(seq, rsq, pos, prs, neg, nrs)
+    out = m._launch_fwd(*ids, 0.0, 0, save=True)
+    g1, g2 = torch.randn_like(out["pos_logits"]), torch.randn_like(out["neg_logits"])
+    a = m._launch_bwd(*ids, 0.0, 0, out, None, g1, g2)
+    b = m._launch_bwd(*ids, 0.0, 0, out, None, 2 * g1, 2 * g2)
+    dense = slice(m.n_table_pad, m.n_table_pad + m.layout.n_dense)
+    assert torch.equal(b[dense], 2 * a[dense])
+    di = m.layout.d_item
+    assert float((b[:m.layout.n_table] - 2 * a[:m.layout.n_table]).abs().max()) < 1e-4
+    rows = a[:m.layout.n_table].view(-1, di)
+    assert float(rows[0].abs().max()) == 0.0
+    touched = torch.unique(torch.cat([seq.flatten(), pos.flatten(), neg.flatten()]))
+    mask = torch.ones(rows.shape[0], dtype=torch.bool, device="cuda")
+    mask[touched] = False
+    assert float(rows[mask].abs().max()) == 0.0
+
+
+def test_c3_fused_step_equals_autograd_step_and_learns(c3):
+    import srfrd_amd
+    from tests.helpers import adam_tolerance
+    kind, m, (u, seq, rsq, pos, prs, neg, nrs) = c3
+    m1, m2 = copy.deepcopy(m), copy.deepcopy(m)
+    m1.dropout_rate = m2.dropout_rate = 0.0
+    m1.train(); m2.train()
+    tr = srfrd_amd.FusedTrainer(m1, B, L, use_graph=True)
+    opt = torch.optim.Adam(m2.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    crit = torch.nn.BCEWithLogitsLoss()
+    losses, hist = [], []
+    for step in range(3):
+        l1 = tr.step(u, seq, rsq, pos, prs, neg, nrs)
+        h, pl, nl = m2(u, seq, rsq, pos, prs, neg, nrs)
+        idx = torch.where(pos != 0)
+        l2 = crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
+        opt.zero_grad()
+        l2.backward()
+        hist.append({k: p.grad.detach().clone() for k, p in m2.named_parameters()})
+        opt.step()
+        assert abs(float(l1) - float(l2.detach())) < 1e-5
+        losses.append(float(l1))
+    assert losses[2] < losses[0]
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        d = (sd1[k] - sd2[k]).abs().double().cpu()
+        bad = d > adam_tolerance([g[k].cpu() for g in hist])
+        assert not bool(bad.any()), (k, float(d[bad].max()), int(bad.sum()))
+
+
+def test_c3_untrained_hit_rate_is_chance(c3):
+    import srfrd_amd
+    kind, m, (u, seq, rsq, pos, prs, neg, nrs) = c3
+    cand = srfrd_amd.eval_candidates(I, seq, pos[:, -1], 100, seed=3)
+    ndcg, hr = srfrd_amd.evaluate_batches(m, [(u, seq, rsq, cand)])
+    assert 0.04 < hr < 0.18
+    idx, val = m.topk(u, seq, rsq, k=10)
+    assert idx.shape == (B, 10) and bool((val[:, :-1] >= val[:, 1:]).all()) and bool((idx >= 1).all())
