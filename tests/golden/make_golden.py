@@ -22,7 +22,7 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 import SRFR_model as ref  # noqa: E402
 
-I, L, B = 120, 20, 8
+I, L, B = 1000, 20, 8            # C1's catalog (BASELINE configs[0]: 1k items, seq_len 20)
 D_ITEM, D_FAKE, NB, NH = 45, 5, 2, 1
 
 
@@ -150,5 +150,49 @@ def main():
     print("labels_edge done")
 
 
+def c2_checksum():
+    """BASELINE configs[1] / [2] at FULL size (50 000 items, seq_len 50, batch 512) through the REFERENCE's forward: the
+    weights are too large to store (10 MB per kind), so the fixture pins the construction instead - under
+    ``torch.manual_seed(seed)`` the drop-in classes create their parameter containers in the reference's order, so the
+    same seed + ``xavier_normal_`` loop reproduces the reference's weights bit for bit (verified through the stored
+    weight checksums) - and stores the reference's outputs on the seeded synthetic batch: full pos / neg logits and the
+    last-position hidden states."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from srfrd_amd.sampler import synthetic_batch
+    I2, L2, B2 = 50_000, 50, 512
+    out = {"meta": np.array([I2, L2, B2], np.int64)}
+    for k_i, kind in enumerate(["SASRec", "SRFRN", "SRFU_B"]):
+        seed = 700 + k_i
+        torch.manual_seed(seed)
+        if kind == "SASRec":
+            model = ref.SASRec(I2, L2, 50, 0.5, NB, NH, "cpu")
+        elif kind == "SRFRN":
+            model = ref.SRFRN(I2, L2, 45, 5, 0.5, NB, NH, "cpu")
+        else:
+            model = ref.SRFU_B(I2, L2, 50, 3, 0.5, NB, NH, "cpu")
+        for _, p in model.named_parameters():          # reference trainer.py:364-369
+            try:
+                torch.nn.init.xavier_normal_(p.data)
+            except Exception:
+                pass
+        model.eval()
+        u, seq, rsq, pos, prs, neg, nrs = synthetic_batch(I2, L2, B2, seed=11 + k_i)
+        with torch.no_grad():
+            h, pl, nl = model(u, seq, rsq, pos, prs, neg, nrs)
+        out[f"{kind}/seed"] = np.array([seed, 11 + k_i], np.int64)
+        out[f"{kind}/w_sum"] = np.array([float(v.double().sum()) for v in model.state_dict().values()], np.float64)
+        out[f"{kind}/w_abs"] = np.array([float(v.double().abs().sum()) for v in model.state_dict().values()], np.float64)
+        out[f"{kind}/pos_logits"] = pl.numpy()
+        out[f"{kind}/neg_logits"] = nl.numpy()
+        out[f"{kind}/h_last"] = h[:, -1].numpy()
+        out[f"{kind}/h_sum"] = np.array([float(h.double().sum()), float((h.double() ** 2).sum())], np.float64)
+    path = os.path.join(HERE, "c2_reference_outputs.npz")
+    np.savez_compressed(path, **out)
+    print("c2 ->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if "--c2" in sys.argv:
+        c2_checksum()
+    else:
+        main()

@@ -8,7 +8,7 @@ from oracle import srfrd_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KINDS = O.KINDS
-G_I, G_L, G_B = 120, 20, 8
+G_I, G_L, G_B = 1000, 20, 8
 
 
 def golden_cfg(kind, dropout=0.0):

@@ -44,7 +44,7 @@ def test_trainer_style_init_and_cpu_call_fails_loudly(kind):
         m(None, ids, ids, ids, ids, ids, ids)
     assert hasattr(m, "predict") and hasattr(m, "forward")
     if kind != "SASRec":
-        assert m.embedding_layer.item_embed.weight.shape[0] == 121      # attribute path used at SRFR_model.py:130
+        assert m.embedding_layer.item_embed.weight.shape[0] == 1001     # attribute path used at SRFR_model.py:130
 
 
 def test_srfu_base_class_is_abstract_like_the_reference():
