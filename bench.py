@@ -27,6 +27,10 @@ WORKLOADS = {
     "C3u": dict(kind="SRFU_B", n_items=50_000, seq_len=50, batch=512, hidden=50, labels=3, blocks=2, heads=1, dropout=0.5),
     "C4": dict(kind="SASRec", n_items=200_000, seq_len=100, batch=512, hidden=50, blocks=2, heads=1, dropout=0.5),
     "C5": dict(kind="SASRec", n_items=1_000_000, seq_len=200, batch=512, hidden=50, blocks=2, heads=1, dropout=0.5),
+    # the bf16 item-table shadow (configs[1] / [4] say "bf16"): a SECOND workload, never reported in place of the fp32 line
+    "C2_bf16_table": dict(C2, bf16_table=True),
+    "C5_bf16_table": dict(kind="SASRec", n_items=1_000_000, seq_len=200, batch=512, hidden=50, blocks=2, heads=1, dropout=0.5,
+                          bf16_table=True),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (matrix) dense
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
@@ -257,6 +261,8 @@ def explore(args, cfg, model, dev, rank):
     import srfrd_amd
     B, L = cfg["batch"], cfg["seq_len"]
     u, seq, rsq, pos, prs, neg, nrs = srfrd_amd.synthetic_batch(cfg["n_items"], L, B, seed=1, rank=rank, device=dev)
+    if cfg.get("bf16_table"):
+        model.use_bf16_table()
     if args.predict:
         model.eval()
         fn = lambda: model.topk(u, seq, rsq, k=10)
@@ -273,7 +279,8 @@ def explore(args, cfg, model, dev, rank):
     el = time.perf_counter() - t0
     print(json.dumps({"workload": args.workload, "mode": "predict_top10" if args.predict else "train_step",
                       "kind": cfg["kind"], "sequences_per_s": B * args.steps / el, "ms_per_step": el / args.steps * 1e3,
-                      "batch": B, "seq_len": L, "n_items": cfg["n_items"], "contract_line": False}), flush=True)
+                      "batch": B, "seq_len": L, "n_items": cfg["n_items"], "item_table": "bf16 shadow" if cfg.get("bf16_table") else "fp32",
+                      "contract_line": False}), flush=True)
 
 
 def time_kernels(tr, batches, steps):

@@ -64,6 +64,11 @@ typedef struct srfrd_block_off {
 typedef struct srfrd_layout {
   int32_t kind, n_items, max_len, d_item, d_fake, D, d_out, n_labels, n_blocks, n_heads;
   int32_t side_rows, side_cols; /* fake_embed (3,d_fake) | user_label_embed (n_labels,D) | none (0,0) */
+  int32_t table_bf16;           /* 0: every `item_table` argument is the fp32 parameter (n_items+1, d_item).  1: it is the
+                                   bf16 SHADOW of it (uint16_t, same shape; BASELINE configs[1] / [4] "bf16" table): the
+                                   forward / backward / ranking GATHERS read half the bytes; gradients, the fp32 master
+                                   and Adam are unchanged (the optimizer launchers rewrite the shadow) */
+  int32_t reserved0;
   int64_t off_pos;              /* pos_embed / pos_emb                  (max_len, d_item) */
   int64_t off_side;             /* fake_embed / user_label_embed        (side_rows, side_cols) */
   srfrd_block_off blk[SRFRD_MAX_BLOCKS];
@@ -118,7 +123,8 @@ int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packe
  * masked-BCE partial sums.  Replaces reference SRFR_model.py:92-142 (and the SRFRN / SRFU / SASRec twins)
  * plus the loss terms of reference trainer.py:36-38.
  *
- *  item_table (n_items+1, d_item), dense (n_dense)           parameters;  packed: srfrd_pack_weights(dense)
+ *  item_table (n_items+1, d_item) fp32 - or its bf16 shadow when lay->table_bf16 -, dense (n_dense) parameters;
+ *    packed: srfrd_pack_weights(dense)
  *  input_ids, fake_ids (B,L); fake_ids may be NULL (SASRec ignores it; SRFR/SRFRN treat NULL as all-zero,
  *    reference SRFR_model.py:27-28)
  *  pos_ids/neg_ids (B,L) or NULL (no logits, reference :126-136); pos_fake/neg_fake used by SRFRN only
@@ -131,7 +137,7 @@ int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packe
  *  scratch / scratch_floats: srfrd_scratch_floats() floats of workspace (NULL / 0 when that is 0)
  *  dbg / dbg_seq: debug taps of one sequence (tests only; NULL otherwise)
  */
-int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
+int srfrd_encoder_fwd(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
                       const int64_t* input_ids, const int64_t* fake_ids,
                       const int64_t* pos_ids, const int64_t* pos_fake,
                       const int64_t* neg_ids, const int64_t* neg_fake,
@@ -156,7 +162,7 @@ int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const fl
  *    srfrd_table_reduce sums the rows of each item in a fixed order into grad_table (bitwise reproducible)
  *  grad_slabs (srfrd_bwd_grid(B), n_dense): per-workgroup partial dense gradients (fully overwritten)
  */
-int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
+int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
                       const int64_t* input_ids, const int64_t* fake_ids,
                       const int64_t* pos_ids, const int64_t* pos_fake,
                       const int64_t* neg_ids, const int64_t* neg_fake,
@@ -205,21 +211,28 @@ int srfrd_step_begin(uint32_t* state, double lr, double beta1, double beta2, voi
  * gscale = 1 / stats[2] if stats != NULL (mean over non-pad targets, trainer.py:36-38) else 1.
  * The first n_zero gradient elements (the table, accumulated by atomics) are re-zeroed in the same pass.
  * [i0, i1) = the slice this rank updates (sharded optimizer); pass 0, n for all.
+ * table_bf16 (may be NULL): bf16 shadow of the first n_table parameters (the item table); stepped elements below n_table
+ * are also written there, rounded to nearest even.
  */
 int srfrd_adam_step(float* param, float* grad, float* m, float* v, int64_t n, int64_t i0, int64_t i1,
                     int64_t n_zero, double beta1, double beta2, double eps,
-                    const uint32_t* state, const float* stats, void* stream);
+                    const uint32_t* state, const float* stats, uint16_t* table_bf16, int64_t n_table, void* stream);
 
 /*
  * Fused tail of the train step: srfrd_adam_step over the whole flat vector [table | pad | dense] (n floats, the dense
  * part starting at n_table_pad), the stepped encoder weights written straight into `packed` in both fragment forms
  * (what srfrd_pack_weights(dense) would produce; `packed` must have been packed once before), and the optimizer-state
- * advance of srfrd_step_begin for the NEXT step, done by the last block to finish.  `state` holds 32 words here:
+ * advance of srfrd_step_begin for the NEXT step, done by the last block to finish; table_bf16 (may be NULL) = the bf16 shadow
+ * of the item table (lay->n_table elements), rewritten with the stepped rows in the same pass.  `state` holds 32 words here:
  * state[6] and state[8..23] are the ticket counters of that hand-off (zero between launches).  Replaces optimizer.step() of reference trainer.py:41.
  */
 int srfrd_adam_pack_step(const srfrd_layout* lay, float* param, float* grad, float* m, float* v, int64_t n,
                          int64_t n_table_pad, int64_t n_zero, double lr, double beta1, double beta2, double eps,
-                         uint32_t* state, const float* stats, float* packed, void* stream);
+                         uint32_t* state, const float* stats, float* packed, uint16_t* table_bf16, void* stream);
+
+/* bf16 shadow of an fp32 vector (round to nearest even): out[i] = bf16(src[i]), i < n.  Builds / refreshes the item-table
+ * shadow that lay->table_bf16 = 1 launches gather from (the fused optimizer keeps it current by itself). */
+int srfrd_table_to_bf16(const float* src, int64_t n, uint16_t* out, void* stream);
 
 /* loss = stats[0]/stats[2] + stats[1]/stats[2] -> loss_out[0] (reference trainer.py:36-38). */
 int srfrd_loss_finalize(const float* stats, float* loss_out, void* stream);
@@ -244,7 +257,7 @@ int srfrd_check_ids(const int64_t* item_a, const int64_t* item_b, const int64_t*
  * E = item row (SRFRN: item row || fake_embed[user_label[b]]).  cand is (n_cand) shared by all users
  * (cand_stride = 0) or (B, n_cand) per user (cand_stride = n_cand).  logits (B, n_cand).
  */
-int srfrd_predict_logits(const srfrd_layout* lay, const float* item_table, const float* dense,
+int srfrd_predict_logits(const srfrd_layout* lay, const void* item_table, const float* dense,
                          const float* hidden, int B, int L, const int64_t* cand, int n_cand, int64_t cand_stride,
                          const int64_t* user_label, float* logits, void* stream);
 
@@ -254,7 +267,7 @@ int srfrd_predict_logits(const srfrd_layout* lay, const float* item_table, const
  * topk_val (B,k).  workspace: srfrd_topk_workspace_bytes().  exclude_pad != 0 skips item 0.
  */
 int64_t srfrd_topk_workspace_bytes(int B, int k, int64_t n_rows);
-int srfrd_logits_topk(const srfrd_layout* lay, const float* item_table, const float* dense,
+int srfrd_logits_topk(const srfrd_layout* lay, const void* item_table, const float* dense,
                       const float* hidden, int B, int L, int64_t item_lo, int64_t item_hi, int exclude_pad,
                       const int64_t* user_label, int k, int64_t* topk_idx, float* topk_val,
                       void* workspace, void* stream);

@@ -48,6 +48,7 @@ class Cfg:
     num_blocks: int = 2
     num_heads: int = 1
     dropout: float = 0.0
+    table_bf16: bool = False   # the build's bf16 item-table shadow (BASELINE configs[1] / [4]; no reference counterpart)
 
     @property
     def D(self) -> int:
@@ -75,6 +76,17 @@ def key_side(cfg):
     if cfg.kind.startswith("SRFU"):
         return "embedding_layer.user_label_embed.weight"
     return None
+
+
+def item_table(cfg, sd):
+    """The item table as every GATHER sees it.  ``cfg.table_bf16`` (the build's bf16-shadow variant of BASELINE configs[1] and
+    [4]; the reference has no counterpart - its table is fp32): each element rounded to bf16 (nearest even) for the
+    forward value, gradient passed straight to the fp32 master, which is what the kernels do - they gather from the
+    shadow, scatter the gradient into the fp32 gradient of the master, and Adam steps the master."""
+    w = sd[key_item(cfg)]
+    if not cfg.table_bf16:
+        return w
+    return w + (w.detach().to(torch.bfloat16).to(torch.float32) - w.detach())
 
 
 # ----------------------------------------------------------------------------------------------
@@ -169,7 +181,7 @@ def layer_norm(x, w, b):
 def embed(cfg: Cfg, sd, input_ids, fake_ids, masks=None):
     """steps 1-4 of SURVEY 3.4 -> (B,L,D) masked input embeddings."""
     B, L = input_ids.shape
-    item = sd[key_item(cfg)]
+    item = item_table(cfg, sd)
     pos = sd[key_pos(cfg)]
     x = item[input_ids]
     if cfg.kind == "SASRec":
@@ -259,7 +271,7 @@ def forward(cfg: Cfg, sd, input_ids, fake_ids, pos_ids=None, pos_fake=None, neg_
     if cfg.kind == "SRFR":
         x = x @ sd["last_conv.weight"].squeeze(-1).T + sd["last_conv.bias"]
     h = layer_norm(x, sd["last_layernorm.weight"], sd["last_layernorm.bias"])
-    item = sd[key_item(cfg)]
+    item = item_table(cfg, sd)
 
     def tgt(ids, fids):
         e = item[ids]
@@ -276,7 +288,7 @@ def predict(cfg: Cfg, sd, input_ids, fake_ids, cand: torch.Tensor) -> torch.Tens
     """cand (I_c,) shared or (B,I_c) per user -> logits (B,I_c)  (reference squeezes B==1 to (I_c,))."""
     h, _, _ = forward(cfg, sd, input_ids, fake_ids)
     hl = h[:, -1, :]
-    e = sd[key_item(cfg)][cand]
+    e = item_table(cfg, sd)[cand]
     if cfg.kind == "SRFRN":
         lab = srfrn_predict_label(fake_ids)
         fe = sd[key_side(cfg)][lab]                                    # (B,d_f)

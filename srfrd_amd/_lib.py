@@ -24,7 +24,7 @@ class BlockOff(C.Structure):
 
 class Layout(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("kind", "n_items", "max_len", "d_item", "d_fake", "D", "d_out", "n_labels",
-                                          "n_blocks", "n_heads", "side_rows", "side_cols")]
+                                          "n_blocks", "n_heads", "side_rows", "side_cols", "table_bf16", "reserved0")]
                 + [("off_pos", C.c_int64), ("off_side", C.c_int64), ("blk", BlockOff * MAX_BLOCKS),
                    ("off_lc_w", C.c_int64), ("off_lc_b", C.c_int64), ("off_ll_w", C.c_int64), ("off_ll_b", C.c_int64),
                    ("n_dense", C.c_int64), ("n_table", C.c_int64)])
@@ -52,8 +52,9 @@ SIGNATURES = {
     "srfrd_reduce_dense": (_i, [_P, _i, _i64, _P, _P, _i, _P, _P, _P]),
     "srfrd_loss_stats": (_i, [_P, _i, _P, _P, _P]),
     "srfrd_step_begin": (_i, [_P, _d, _d, _d, _P]),
-    "srfrd_adam_step": (_i, [_P, _P, _P, _P, _i64, _i64, _i64, _i64, _d, _d, _d, _P, _P, _P]),
-    "srfrd_adam_pack_step": (_i, [_LP, _P, _P, _P, _P, _i64, _i64, _i64, _d, _d, _d, _d, _P, _P, _P, _P]),
+    "srfrd_adam_step": (_i, [_P, _P, _P, _P, _i64, _i64, _i64, _i64, _d, _d, _d, _P, _P, _P, _i64, _P]),
+    "srfrd_adam_pack_step": (_i, [_LP, _P, _P, _P, _P, _i64, _i64, _i64, _d, _d, _d, _d, _P, _P, _P, _P, _P]),
+    "srfrd_table_to_bf16": (_i, [_P, _i64, _P, _P]),
     "srfrd_loss_finalize": (_i, [_P, _P, _P]),
     "srfrd_user_labels": (_i, [_i, _P, _i, _i, _P, _P]),
     "srfrd_check_ids": (_i, [_P, _P, _P, _P, _P, _P, _i64, _i64, _i64, _P, _P]),

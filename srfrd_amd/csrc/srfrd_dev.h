@@ -61,6 +61,16 @@ __host__ __device__ __forceinline__ Geom make_geom(int L, int D) {
 
 __host__ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 
+// bf16 <-> f32 (round to nearest even on the way down: hipcc lowers the cast to v_cvt_pk_bf16_f32, NaN stays NaN)
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+// The item table as the gathers see it: the fp32 parameter, or its bf16 shadow (srfrd_layout::table_bf16) at half the bytes
+struct ItemTable {
+  const float* f;
+  const uint16_t* h;
+  __device__ __forceinline__ float operator()(int64_t i) const { return h != nullptr ? bf16_to_f32(h[i]) : f[i]; }
+};
+
 // An id as the kernels use it: clamped (in 64 bits, before the narrowing) into [0, hi], so that no input - an item id
 // beyond the model's table, a negative id, a fake id above 2 - can turn a gather into an out-of-bounds read or a
 // gradient scatter into a write over a neighbouring parameter.  Out-of-range ids are REPORTED by srfrd_check_ids (the

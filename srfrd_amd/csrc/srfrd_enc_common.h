@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 #include "srfrd_dev.h"
@@ -12,7 +13,8 @@ namespace SRFRD_NS {
 
 struct EncArgs {
   Dims dm;
-  const float* table;
+  const float* table;       // fp32 item table, or NULL when the gathers read the bf16 shadow
+  const uint16_t* table16;  // bf16 shadow of the item table (srfrd_layout::table_bf16), or NULL
   const float* dense;
   const float* packed;      // srfrd_pack_weights output (MFMA-fragment-ordered weights)
   const int64_t *in_ids, *fk_ids, *pos_ids, *pos_fk, *neg_ids, *neg_fk;
@@ -200,7 +202,7 @@ __device__ __forceinline__ void tap(const EncArgs& a, int b, int slot, const lds
   return (v >= 64 && v <= 1024 && (v & 63) == 0) ? v : dflt;
 }
 
-[[maybe_unused]] static int fill_args(EncArgs& a, const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
+[[maybe_unused]] static int fill_args(EncArgs& a, const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
                      const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids, const int64_t* pos_fake,
                      const int64_t* neg_ids, const int64_t* neg_fake, int B, int L, double dropout_p, uint32_t seed,
                      const uint32_t* seed_dev, int64_t seq_index0) {
@@ -225,7 +227,8 @@ __device__ __forceinline__ void tap(const EncArgs& a, int b, int slot, const lds
   }
   d.off_lc_w = (int)lay->off_lc_w; d.off_lc_b = (int)lay->off_lc_b; d.off_ll_w = (int)lay->off_ll_w; d.off_ll_b = (int)lay->off_ll_b;
   d.n_dense = (int)lay->n_dense;
-  a.table = item_table;
+  a.table = lay->table_bf16 ? nullptr : (const float*)item_table;
+  a.table16 = lay->table_bf16 ? (const uint16_t*)item_table : nullptr;
   a.dense = dense;
   a.packed = packed;
   a.in_ids = input_ids; a.fk_ids = fake_ids; a.pos_ids = pos_ids; a.pos_fk = pos_fake; a.neg_ids = neg_ids; a.neg_fk = neg_fake;

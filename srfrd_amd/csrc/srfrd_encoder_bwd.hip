@@ -20,7 +20,7 @@ extern "C" int srfrd_bwd_grid(int B) {
   return B < cu ? B : cu;
 }
 
-extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
+extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
                                  const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
                                  const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
                                  double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,

@@ -98,7 +98,7 @@ extern "C" int srfrd_debug_shape(const srfrd_layout* lay, int L, int64_t* slot_f
   return 0;
 }
 
-extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const float* item_table, const float* dense, const float* packed,
+extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
                                  const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
                                  const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
                                  double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,

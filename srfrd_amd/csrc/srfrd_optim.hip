@@ -113,10 +113,31 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p = p - step_size * (m / denom);
 }
 
+// bf16 shadow of four stepped item-table elements starting at i (i is a multiple of 4: one 8-byte store when all four are
+// inside the table)
+__device__ __forceinline__ void shadow_store4(uint16_t* __restrict__ shadow, int64_t i, int64_t n_shadow, const float4& p4) {
+  const uint16_t h0 = f32_to_bf16(p4.x), h1 = f32_to_bf16(p4.y), h2 = f32_to_bf16(p4.z), h3 = f32_to_bf16(p4.w);
+  if (i + 3 < n_shadow) {
+    *reinterpret_cast<uint2*>(shadow + i) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+  } else {
+    shadow[i] = h0;
+    if (i + 1 < n_shadow) shadow[i + 1] = h1;
+    if (i + 2 < n_shadow) shadow[i + 2] = h2;
+  }
+}
+
+__global__ void __launch_bounds__(256) table_to_bf16_kernel(const float* __restrict__ src, int64_t n, uint16_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nvec = n >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nvec; q += stride)
+    shadow_store4(out, q << 2, n, *reinterpret_cast<const float4*>(src + (q << 2)));
+  for (int64_t i = (nvec << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = f32_to_bf16(src[i]);
+}
+
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
                                                   float* __restrict__ v, int64_t i0, int64_t i1, int64_t n_zero, float b1,
                                                   float b2, float eps, const uint32_t* __restrict__ state,
-                                                  const float* __restrict__ stats) {
+                                                  const float* __restrict__ stats, uint16_t* __restrict__ shadow, int64_t n_shadow) {
   const float step_size = ((const float*)state)[4];
   const float bc2s = ((const float*)state)[5];
   const float gscale = stats ? 1.0f / stats[2] : 1.0f;
@@ -138,6 +159,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
     *reinterpret_cast<float4*>(v + i) = v4;
     if (i + 3 < n_zero) *reinterpret_cast<float4*>(grad + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     else if (i < n_zero) for (int k = 0; k < 4; ++k) if (i + k < n_zero) grad[i + k] = 0.f;
+    if (shadow != nullptr && i < n_shadow) shadow_store4(shadow, i, n_shadow, p4);
   }
   // scalar tail
   const int64_t tail0 = i0 + (nvec << 2);
@@ -146,6 +168,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ param, fl
     adam_one(p, grad[i] * gscale, mm, vv, b1, b2, eps, step_size, bc2s);
     param[i] = p; m[i] = mm; v[i] = vv;
     if (i < n_zero) grad[i] = 0.f;
+    if (shadow != nullptr && i < n_shadow) shadow[i] = f32_to_bf16(p);
   }
 }
 
@@ -186,7 +209,8 @@ __global__ void __launch_bounds__(512) adam_pack_kernel(float* __restrict__ para
                                                        float* __restrict__ v, int64_t n, int64_t n_tab, int64_t n_zero, float b1,
                                                        float b2, float eps, uint32_t* __restrict__ state,
                                                        const float* __restrict__ stats, Dims dims, float* __restrict__ packed,
-                                                       double lr, double b1d, double b2d) {
+                                                       double lr, double b1d, double b2d, uint16_t* __restrict__ shadow,
+                                                       int64_t n_shadow) {
   const float step_size = ((const float*)state)[4];
   const float bc2s = ((const float*)state)[5];
   const float gscale = stats ? 1.0f / stats[2] : 1.0f;
@@ -208,6 +232,7 @@ __global__ void __launch_bounds__(512) adam_pack_kernel(float* __restrict__ para
     *reinterpret_cast<float4*>(v + i) = v4;
     if (i + 3 < n_zero) *reinterpret_cast<float4*>(grad + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     else if (i < n_zero) for (int k = 0; k < 4; ++k) if (i + k < n_zero) grad[i + k] = 0.f;
+    if (shadow != nullptr && i < n_shadow) shadow_store4(shadow, i, n_shadow, p4);
     if (i + 3 >= w_lo) {
       pack_scatter(dims, i - n_tab, p4.x, packed);
       pack_scatter(dims, i + 1 - n_tab, p4.y, packed);
@@ -220,6 +245,7 @@ __global__ void __launch_bounds__(512) adam_pack_kernel(float* __restrict__ para
     adam_one(p, grad[i] * gscale, mm, vv, b1, b2, eps, step_size, bc2s);
     param[i] = p; m[i] = mm; v[i] = vv;
     if (i < n_zero) grad[i] = 0.f;
+    if (shadow != nullptr && i < n_shadow) shadow[i] = f32_to_bf16(p);
     if (i >= w_lo) pack_scatter(dims, i - n_tab, p, packed);
   }
   // The block that finishes last advances (t, bias corrections, dropout seed): every block has read them by then.
@@ -279,22 +305,30 @@ extern "C" int srfrd_step_begin(uint32_t* state, double lr, double beta1, double
   return (int)hipGetLastError();
 }
 
+extern "C" int srfrd_table_to_bf16(const float* src, int64_t n, uint16_t* out, void* stream) {
+  if (!src || !out || n <= 0) return SRFRD_E_ARG;
+  int64_t grid = ((n >> 2) + 1 + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(table_to_bf16_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src, n, out);
+  return (int)hipGetLastError();
+}
+
 extern "C" int srfrd_adam_step(float* param, float* grad, float* m, float* v, int64_t n, int64_t i0, int64_t i1,
                                int64_t n_zero, double beta1, double beta2, double eps, const uint32_t* state,
-                               const float* stats, void* stream) {
+                               const float* stats, uint16_t* table_bf16, int64_t n_table, void* stream) {
   if (!param || !grad || !m || !v || !state || n <= 0 || i0 < 0 || i1 > n || i0 > i1 || (i0 & 3)) return SRFRD_E_ARG;
   if (i0 == i1) return 0;
   const int64_t nvec = ((i1 - i0) >> 2) + 1;
   int64_t grid = (nvec + 255) / 256;
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(adam_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, i0, i1, n_zero,
-                     (float)beta1, (float)beta2, (float)eps, state, stats);
+                     (float)beta1, (float)beta2, (float)eps, state, stats, table_bf16, table_bf16 ? n_table : 0);
   return (int)hipGetLastError();
 }
 
 extern "C" int srfrd_adam_pack_step(const srfrd_layout* lay, float* param, float* grad, float* m, float* v, int64_t n,
                                     int64_t n_table_pad, int64_t n_zero, double lr, double beta1, double beta2, double eps,
-                                    uint32_t* state, const float* stats, float* packed, void* stream) {
+                                    uint32_t* state, const float* stats, float* packed, uint16_t* table_bf16, void* stream) {
   if (!lay || !param || !grad || !m || !v || !state || !packed || n <= 0 || n_table_pad < 0 || (n_table_pad & 3) ||
       n_table_pad + lay->n_dense > n)
     return SRFRD_E_ARG;
@@ -310,7 +344,8 @@ extern "C" int srfrd_adam_pack_step(const srfrd_layout* lay, float* param, float
   int64_t grid = ((n >> 2) + 1 + 511) / 512;
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(adam_pack_kernel, dim3((int)grid), dim3(512), 0, (hipStream_t)stream, param, grad, m, v, n, n_table_pad,
-                     n_zero, (float)beta1, (float)beta2, (float)eps, state, stats, d, packed, lr, beta1, beta2);
+                     n_zero, (float)beta1, (float)beta2, (float)eps, state, stats, d, packed, lr, beta1, beta2, table_bf16,
+                     table_bf16 ? lay->n_table : 0);
   return (int)hipGetLastError();
 }
 

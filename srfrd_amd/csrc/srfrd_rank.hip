@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) check_ids_kernel(IdSets s, int64_t n, int
 // ---------------------------------------------------------------------------------------------
 // predict: one wave per (user, candidate); lane = channel
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) predict_logits_kernel(srfrd_layout ly, const float* __restrict__ table,
+__global__ void __launch_bounds__(256) predict_logits_kernel(srfrd_layout ly, const void* __restrict__ table_any,
                                                             const float* __restrict__ dense, const float* __restrict__ hidden,
                                                             int B, int L, const int64_t* __restrict__ cand, int n_cand,
                                                             int64_t cand_stride, const int64_t* __restrict__ user_label,
@@ -58,8 +58,9 @@ __global__ void __launch_bounds__(256) predict_logits_kernel(srfrd_layout ly, co
   const int dout = ly.d_out, di = ly.d_item;
   const float h = lane < dout ? hidden[((int64_t)b * L + (L - 1)) * dout + lane] : 0.f;
   const int64_t id = clamp_id(cand[(int64_t)b * cand_stride + i], ly.n_items);
+  const ItemTable table{ly.table_bf16 ? nullptr : (const float*)table_any, ly.table_bf16 ? (const uint16_t*)table_any : nullptr};
   float e = 0.f;
-  if (lane < di) e = table[id * di + lane];
+  if (lane < di) e = table(id * di + lane);
   else if (ly.kind == SRFRD_SRFRN && lane < ly.D) e = dense[ly.off_side + clamp_id(user_label[b], 2) * ly.d_fake + (lane - di)];
   const float s = wave_sum(h * e);
   if (lane == 0) logits[w] = s;
@@ -88,7 +89,8 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { retur
 
 struct TopkArgs {
   srfrd_layout ly;
-  const float *table, *dense, *hidden;
+  const void* table;            // fp32 item table, or its bf16 shadow when ly.table_bf16
+  const float *dense, *hidden;
   const int64_t* user_label;
   int B, L, exclude_pad, k, n_chunks, user_splits;
   int64_t item_lo, item_hi;
@@ -101,11 +103,13 @@ struct TopkArgs {
 // contiguous global [rows][cols] -> LDS [rows][ld] with ITER loads in flight per thread (clamped indices, no predicate
 // between the loads): a plain `for (i = tid; ...) lds[..] = g[i]` copy pays one L2 / HBM round trip per iteration -
 // 108 of them for a 512-row chunk, which was 85 % of this kernel's time.
-template <int ITER>
-__device__ __forceinline__ void stage_rows(lds_f* dst, int ld, const float* src, int rows, int cols) {
+__device__ __forceinline__ float as_f32(float v) { return v; }
+__device__ __forceinline__ float as_f32(uint16_t v) { return bf16_to_f32(v); }
+template <int ITER, class T>
+__device__ __forceinline__ void stage_rows(lds_f* dst, int ld, const T* src, int rows, int cols) {
   const int n = rows * cols, nthr = blockDim.x, tid = threadIdx.x;
   for (int base = 0; base < n; base += ITER * nthr) {
-    float v[ITER];
+    T v[ITER];
 #pragma unroll
     for (int u = 0; u < ITER; ++u) v[u] = src[min(base + u * nthr + tid, n - 1)];
 #pragma unroll
@@ -113,10 +117,16 @@ __device__ __forceinline__ void stage_rows(lds_f* dst, int ld, const float* src,
       const int i = base + u * nthr + tid;
       if (i < n) {
         const int r = i / cols, c = i - r * cols;
-        dst[r * ld + c] = v[u];
+        dst[r * ld + c] = as_f32(v[u]);
       }
     }
   }
+}
+// a chunk of item rows from the table as the launch sees it (fp32, or the bf16 shadow)
+template <int ITER>
+__device__ __forceinline__ void stage_item_rows(lds_f* dst, int ld, const srfrd_layout& ly, const void* table, int64_t row0, int rows) {
+  if (ly.table_bf16) stage_rows<ITER>(dst, ld, (const uint16_t*)table + row0 * ly.d_item, rows, ly.d_item);
+  else stage_rows<ITER>(dst, ld, (const float*)table + row0 * ly.d_item, rows, ly.d_item);
 }
 
 // stage a chunk of item rows and then, for this workgroup's user tiles, leave the 16 x kChunk logits tile in sS
@@ -140,7 +150,7 @@ __device__ __forceinline__ void topk_tiles(const TopkArgs& a, F&& per_tile) {
     const int r = idx / DSi, c = idx - r * DSi;
     if (r >= n_here || c >= di) sE[idx] = 0.f;
   }
-  stage_rows<8>(sE, DSi, a.table + i0 * di, n_here, di);
+  stage_item_rows<8>(sE, DSi, a.ly, a.table, i0, n_here);
   for (int idx = tid; idx < 16 * (DSi - di); idx += blockDim.x) {       // k-padding columns of the user rows
     const int r = idx / (DSi - di), c = di + idx - r * (DSi - di);
     sH[r * DSi + c] = 0.f;
@@ -210,7 +220,7 @@ __device__ __forceinline__ void topk_stream(const TopkArgs& a, BEG&& begin, ELEM
     const int r = idx / DSi, c = idx - r * DSi;
     if (r >= n_here || c >= di) sE[idx] = 0.f;
   }
-  stage_rows<8>(sE, DSi, a.table + i0 * di, n_here, di);
+  stage_item_rows<8>(sE, DSi, a.ly, a.table, i0, n_here);
   for (int idx = tid; idx < 2 * 16 * (DSi - di); idx += nthr) {        // k-padding columns of the user rows
     const int r = idx / (DSi - di), c = di + idx - r * (DSi - di);
     sH[r * DSi + c] = 0.f;
@@ -399,7 +409,7 @@ __device__ __forceinline__ void wave_select_topk(lds_f* sc, const int* ids, int 
   }
 }
 
-__global__ void __launch_bounds__(256) topk_stage1_kernel(srfrd_layout ly, const float* __restrict__ table,
+__global__ void __launch_bounds__(256) topk_stage1_kernel(srfrd_layout ly, const void* __restrict__ table,
                                                          const float* __restrict__ dense, const float* __restrict__ hidden,
                                                          int B, int L, int64_t item_lo, int64_t item_hi, int exclude_pad,
                                                          const int64_t* __restrict__ user_label, int k, int n_chunks,
@@ -548,7 +558,7 @@ extern "C" int srfrd_user_labels(int kind, const int64_t* fake_ids, int B, int L
   return (int)hipGetLastError();
 }
 
-extern "C" int srfrd_predict_logits(const srfrd_layout* lay, const float* item_table, const float* dense,
+extern "C" int srfrd_predict_logits(const srfrd_layout* lay, const void* item_table, const float* dense,
                                     const float* hidden, int B, int L, const int64_t* cand, int n_cand, int64_t cand_stride,
                                     const int64_t* user_label, float* logits, void* stream) {
   if (!lay || !item_table || !dense || !hidden || !cand || !logits || B <= 0 || L <= 0 || n_cand <= 0) return SRFRD_E_ARG;
@@ -575,7 +585,7 @@ extern "C" int64_t srfrd_topk_workspace_bytes(int B, int k, int64_t n_rows) {
   return topk_off(B, k, n_chunks, 5);
 }
 
-extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const float* item_table, const float* dense,
+extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const void* item_table, const float* dense,
                                  const float* hidden, int B, int L, int64_t item_lo, int64_t item_hi, int exclude_pad,
                                  const int64_t* user_label, int k, int64_t* topk_idx, float* topk_val, void* workspace,
                                  void* stream) {

@@ -108,6 +108,8 @@ class _SRFRDBase(nn.Module):
         self._packed = None
         self._scratch = None
         self._err = None
+        self._table16 = None     # bf16 shadow of the item table (use_bf16_table)
+        self._lay16 = None
         # "lazy": every call launches srfrd_check_ids on its id tensors and check_ids() (called by evaluation(), or by
         # the user at any synchronisation point) raises; "eager": raise at the call itself like nn.Embedding does (one
         # host sync per call); None: no validation launch (the kernels still clamp ids, so memory stays safe)
@@ -181,9 +183,45 @@ class _SRFRDBase(nn.Module):
         assert covered == lay.n_table + lay.n_dense, "parameter list does not match the dense layout"
         self._flat, self._slots = flat, slots
 
+    # ---- bf16 item-table shadow (BASELINE configs[1] / [4] "bf16"; no reference counterpart: its table is fp32)
+    def use_bf16_table(self, on: bool = True):
+        """Gather item rows (embedding, pos / neg targets, predict / top-k candidates) from a bf16 shadow of the item
+        table: half the gather bytes.  The parameter stays fp32 (state_dict, gradients, Adam unchanged); the shadow is
+        rebuilt from it before every forward of the module path and rewritten by the fused optimizer in FusedTrainer.
+        Forward values then carry bf16-rounded embeddings (parity is held against the oracle with ``table_bf16``)."""
+        self._ensure_flat()
+        if on:
+            lay16 = _lib.Layout.from_buffer_copy(bytes(self.layout))
+            lay16.table_bf16 = 1
+            self._lay16 = lay16
+            self._table16 = torch.empty(self.layout.n_table, device=self._flat.device, dtype=torch.int16)
+            self.refresh_bf16_table()
+        else:
+            self._lay16 = self._table16 = None
+        return self
+
+    @property
+    def bf16_table(self) -> bool:
+        return self._table16 is not None
+
+    def refresh_bf16_table(self):
+        if self._table16 is not None:
+            if self._table16.device != self._flat.device:
+                self._table16 = torch.empty(self.layout.n_table, device=self._flat.device, dtype=torch.int16)
+            check(_lib.lib().srfrd_table_to_bf16(ptr(self._flat), self.layout.n_table, ptr(self._table16), _stream()),
+                  "srfrd_table_to_bf16")
+
+    def _table_args(self):
+        """(layout, item-table pointer) as the gathering launchers take them: fp32 parameter, or the bf16 shadow"""
+        if self._table16 is not None:
+            return self._lay16, ptr(self._table16)
+        return self.layout, ptr(self._flat)
+
     def pack_weights(self):
-        """Refresh the MFMA-fragment-ordered copy of the encoder weights (srfrd_pack_weights) from the parameters."""
+        """Refresh the MFMA-fragment-ordered copy of the encoder weights (srfrd_pack_weights) from the parameters (and the
+        bf16 item-table shadow, when in use)."""
         lay, flat = self.layout, self._flat
+        self.refresh_bf16_table()
         if self._packed is None or self._packed.device != flat.device:
             self._packed = torch.empty(_lib.lib().srfrd_packed_floats(C.byref(lay)), device=flat.device, dtype=torch.float32)
         check(_lib.lib().srfrd_pack_weights(C.byref(lay), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad),
@@ -212,8 +250,9 @@ class _SRFRDBase(nn.Module):
         sa = torch.empty(_lib.lib().srfrd_aux_floats(C.byref(lay), B, L), device=dev, dtype=torch.float32) if save else None
         packed = self.pack_weights()          # parameters may have been stepped since the last call
         scratch, n_scr = self._scratch_for(B, L, backward=False)
+        lay_t, tab = self._table_args()
         check(_lib.lib().srfrd_encoder_fwd(
-            C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(packed),
+            C.byref(lay_t), tab, C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(packed),
             ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
             None, int(seq0), ptr(hidden), ptr(pl), ptr(nl), ptr(sx), ptr(sh), ptr(sa), None, ptr(scratch), n_scr, ptr(dbg),
             int(dbg_seq), _stream()), "srfrd_encoder_fwd")
@@ -228,8 +267,9 @@ class _SRFRDBase(nn.Module):
         n_slabs = _lib.lib().srfrd_bwd_grid(B)
         slabs = torch.empty(n_slabs, lay.n_dense, device=dev, dtype=torch.float32)
         scratch, n_scr = self._scratch_for(B, L, backward=True)
+        lay_t, tab = self._table_args()
         check(_lib.lib().srfrd_encoder_bwd(
-            C.byref(lay), ptr(flat), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(self._packed),
+            C.byref(lay_t), tab, C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(self._packed),
             ptr(inp), ptr(fk), ptr(pos), ptr(pfk), ptr(neg), ptr(nfk), B, L, float(dropout_p), int(seed) & 0xFFFFFFFF,
             None, int(seq0), ptr(out["hidden"]), ptr(out["pos_logits"]), ptr(out["neg_logits"]), ptr(out["save_x"]),
             ptr(out["save_h1"]), ptr(out["save_aux"]), ptr(d_hidden), ptr(d_pl), ptr(d_nl), 0, ptr(gflat), None, ptr(slabs), ptr(scratch), n_scr,

@@ -142,12 +142,12 @@ def _(fake_ids, kind):
 @torch.library.custom_op("srfrd::predict_logits", mutates_args=(), device_types="cuda")
 def predict_logits(hidden: torch.Tensor, cand: torch.Tensor, user_label: Optional[torch.Tensor], model_key: int) -> torch.Tensor:
     m = _model(model_key)
-    lay = m.layout
+    lay, tab = m._table_args()
     B, L = hidden.shape[0], hidden.shape[1]
     stride = 0 if cand.dim() == 1 else cand.shape[1]
     n_cand = cand.shape[-1]
     logits = torch.empty(B, n_cand, device=hidden.device, dtype=torch.float32)
-    check(_lib.lib().srfrd_predict_logits(C.byref(lay), ptr(m._flat), C.c_void_p(m._flat.data_ptr() + 4 * m.n_table_pad), ptr(hidden),
+    check(_lib.lib().srfrd_predict_logits(C.byref(lay), tab, C.c_void_p(m._flat.data_ptr() + 4 * m.n_table_pad), ptr(hidden),
                                           B, L, ptr(cand), n_cand, stride, ptr(user_label), ptr(logits), _stream()),
           "srfrd_predict_logits")
     return logits
@@ -162,13 +162,13 @@ def _(hidden, cand, user_label, model_key):
 def logits_topk(hidden: torch.Tensor, user_label: Optional[torch.Tensor], model_key: int, item_lo: int, item_hi: int, k: int,
                 exclude_pad: bool) -> List[torch.Tensor]:
     m = _model(model_key)
-    lay = m.layout
+    lay, tab = m._table_args()
     B, L = hidden.shape[0], hidden.shape[1]
     dev = hidden.device
     ws = torch.empty(max(_lib.lib().srfrd_topk_workspace_bytes(B, k, item_hi - item_lo), 8), device=dev, dtype=torch.uint8)
     idx = torch.empty(B, k, device=dev, dtype=torch.int64)
     val = torch.empty(B, k, device=dev, dtype=torch.float32)
-    check(_lib.lib().srfrd_logits_topk(C.byref(lay), ptr(m._flat), C.c_void_p(m._flat.data_ptr() + 4 * m.n_table_pad), ptr(hidden), B, L,
+    check(_lib.lib().srfrd_logits_topk(C.byref(lay), tab, C.c_void_p(m._flat.data_ptr() + 4 * m.n_table_pad), ptr(hidden), B, L,
                                        item_lo, item_hi, 1 if exclude_pad else 0, ptr(user_label), k, ptr(idx), ptr(val), ptr(ws),
                                        _stream()), "srfrd_logits_topk")
     return [idx, val]

@@ -129,7 +129,8 @@ class FusedTrainer:
     def _enqueue_fwd(self, slot: int = 0):
         L_, lay, st = _lib.lib(), self.lay, self._stream()
         ids, fk, pfk, nfk, p, seed_dev, seq0 = self._ids_of(slot)
-        check(L_.srfrd_encoder_fwd(C.byref(lay), ptr(self.flat), self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
+        lay_t, tab = self.model._table_args()
+        check(L_.srfrd_encoder_fwd(C.byref(lay_t), tab, self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
                                    ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
                                    ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), ptr(self.loss_part),
                                    ptr(self.scratch), self.n_scratch, None, 0, st), "srfrd_encoder_fwd")
@@ -139,7 +140,8 @@ class FusedTrainer:
     def _enqueue_bwd(self, slot: int = 0):
         L_, lay, st = _lib.lib(), self.lay, self._stream()
         ids, fk, pfk, nfk, p, seed_dev, seq0 = self._ids_of(slot)
-        check(L_.srfrd_encoder_bwd(C.byref(lay), ptr(self.flat), self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
+        lay_t, tab = self.model._table_args()
+        check(L_.srfrd_encoder_bwd(C.byref(lay_t), tab, self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
                                    ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
                                    ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), None, None, None, 1,
                                    ptr(self.grad), ptr(self.contrib), ptr(self.slabs), ptr(self.scratch), self.n_scratch, None, 0, st),
@@ -167,7 +169,8 @@ class FusedTrainer:
         L_, st = _lib.lib(), self._stream()
         check(L_.srfrd_adam_pack_step(C.byref(self.lay), ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v),
                                       self.n_flat, self.n_tab, self.n_tab, self.lr, self.betas[0], self.betas[1], self.eps,
-                                      ptr(self.state), ptr(self.stats), ptr(self.packed), st), "srfrd_adam_pack_step")
+                                      ptr(self.state), ptr(self.stats), ptr(self.packed), ptr(self.model._table16), st),
+              "srfrd_adam_pack_step")
         if self.world > 1:
             check(L_.srfrd_loss_finalize(ptr(self.stats), ptr(self.loss), st), "srfrd_loss_finalize")
 
@@ -180,13 +183,15 @@ class FusedTrainer:
         bias = 4 * ex.i0
         check(L_.srfrd_adam_step(ptr(self.flat_pad), C.c_void_p(self.recv.data_ptr() - bias), C.c_void_p(self.m.data_ptr() - bias),
                                  C.c_void_p(self.v.data_ptr() - bias), ex.n_pad, ex.i0, ex.i1, 0, self.betas[0], self.betas[1],
-                                 self.eps, ptr(self.state), ptr(self.stats), st), "srfrd_adam_step")
+                                 self.eps, ptr(self.state), ptr(self.stats), None, 0, st), "srfrd_adam_step")
 
     def _enqueue_shard_finish(self):
         """sharded form, after the all-gather: fragment-ordered copy of the stepped weights + optimizer-state advance + loss"""
         L_, st = _lib.lib(), self._stream()
         check(L_.srfrd_pack_weights(C.byref(self.lay), self._dense_ptr(self.flat), ptr(self.packed), ptr(self.state), self.lr,
                                     self.betas[0], self.betas[1], st), "srfrd_pack_weights")
+        if self.model._table16 is not None:      # bf16 shadow of the all-gathered item table (every rank needs all rows)
+            check(L_.srfrd_table_to_bf16(ptr(self.flat), self.lay.n_table, ptr(self.model._table16), st), "srfrd_table_to_bf16")
         check(L_.srfrd_loss_finalize(ptr(self.stats), ptr(self.loss), st), "srfrd_loss_finalize")
 
     def _capture(self):
