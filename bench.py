@@ -89,16 +89,55 @@ def host_cores():
 def pmc_traffic(kernel_c_name):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     separate passes, read side doubled as MI355X_MICROARCH.md prescribes for gfx950); None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        ks = json.load(open(path))["kernels"]
-    except Exception:
+    ks = None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            ks = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+            break
+        except Exception:
+            continue
+    if ks is None:
         return None
     stem = kernel_c_name.replace("srfrd_", "") + "_kernel"          # srfrd_encoder_bwd -> encoder_bwd_kernel
     for name, d in ks.items():
         if name.startswith(stem) and "hbm_bytes_per_launch" in d and "<0, 0, 0>" not in name:
             return d["hbm_bytes_per_launch"]["total"]
     return None
+
+
+def metric_parity():
+    """End-to-end HR@10 / NDCG@10 against the REFERENCE (tests/golden/e2e_SASRec.npz: the reference's SASRec trained for 300
+    restated trainer.py steps, then its own evaluation()): the same run through FusedTrainer + DeviceSampler + batched
+    evaluation on this GPU.  -> {|dHR@10|, |dNDCG@10|, ...} or None if the fixture is absent.  Not part of the timed region."""
+    import numpy as np
+    import srfrd_amd
+    path = os.path.join(ROOT, "tests", "golden", "e2e_SASRec.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    g = {k: z[k] for k in z.files}
+    n_users, itemnum, L, B, steps, sampler_seed, _, early = (int(x) for x in g["meta"])
+    w0 = {k[3:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("w0/")}
+    n_items = w0["item_emb.weight"].shape[0] - 1
+    model = srfrd_amd.SASRec(n_items, L, 50, 0.0, 2, 1, "cuda")
+    model.load_state_dict(w0)
+    model = model.cuda().train()
+    data = srfrd_amd.partition(g["rows_user"], g["rows_item"], g["rows_fake"])
+    tr = srfrd_amd.FusedTrainer(model, B, L, use_graph=True)
+    sampler = srfrd_amd.DeviceSampler(data, B, L, seed=sampler_seed, model=tr)
+    for _ in range(steps):
+        sampler.next_batch(out=tr.ids_ring[0])
+        tr.step_slot(0)
+    ndcg, hr = srfrd_amd.evaluation(model, data, L, candidates=g["eval_cand"])
+    # the reference's metric with ties of the held-out item against its own duplicates among the negatives removed (the
+    # reference's unstable argsort places them arbitrarily; tests/test_e2e_metric.py explains), from the reference's logits
+    lg, cand = g["eval_logits"], g["eval_cand"]
+    r = ((lg[:, 1:] > lg[:, :1]) & (cand[:, 1:] != cand[:, :1])).sum(1)
+    hit = r < 10
+    hr_ref, ndcg_ref = float(hit.mean()), float(np.where(hit, 1 / np.log2(r + 2.0), 0.0).mean())
+    return {"model": "SASRec", "train_steps": steps, "eval_users": int(len(r)), "hr10": hr, "hr10_reference": hr_ref,
+            "abs_diff_hr10": abs(hr - hr_ref), "ndcg10": ndcg, "ndcg10_reference": ndcg_ref, "abs_diff_ndcg10": abs(ndcg - ndcg_ref),
+            "hr10_reference_as_reported": float(g["eval_metric"][1])}
 
 
 def cpu_baseline(cfg, budget_s=12.0):
@@ -143,6 +182,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="exploration only; the contract line is C2")
     ap.add_argument("--deterministic", action="store_true", help="deterministic item-table scatter (sort + ordered sums) instead of float atomics")
+    ap.add_argument("--autograd", action="store_true", help="exploration: time the module-level drop-in path (model(...) -> BCE -> "
+                    "loss.backward() -> torch.optim.Adam) instead of FusedTrainer")
     ap.add_argument("--predict", action="store_true", help="time forward + full-catalog top-10 instead of the train step")
     args = ap.parse_args()
 
@@ -178,7 +219,7 @@ def main():
             torch.nn.init.xavier_normal_(p.data)
     model = model.to(dev).train()
     B, L = cfg["batch"], cfg["seq_len"]
-    if args.predict or args.workload != "C2":
+    if args.predict or args.autograd or args.workload != "C2":
         return explore(args, cfg, model, dev, rank)
     # eight synthetic batches resident in the trainer's input ring before the timed region starts (the contract's
     # "inputs already in HBM"): each step consumes one slot in place, as it would a slot a device sampler just filled
@@ -248,6 +289,11 @@ def main():
                                       "achieved": step_bytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": step_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}},
         }
+        if world == 1:
+            try:
+                out["config"]["metric_parity"] = metric_parity()
+            except Exception as e:          # never lose the throughput line to the side measurement
+                out["config"]["metric_parity"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
@@ -266,6 +312,18 @@ def explore(args, cfg, model, dev, rank):
     if args.predict:
         model.eval()
         fn = lambda: model.topk(u, seq, rsq, k=10)
+    elif args.autograd:
+        # the reference's own loop shape (trainer.py:29-41) on the drop-in modules: custom ops + torch autograd + torch Adam
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))
+        crit = torch.nn.BCEWithLogitsLoss()
+
+        def fn():
+            h, pl, nl = model(u, seq, rsq, pos, prs, neg, nrs)
+            opt.zero_grad()
+            idx = torch.where(pos != 0)
+            loss = crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
+            loss.backward()
+            opt.step()
     else:
         tr = srfrd_amd.FusedTrainer(model, B, L, use_graph=not args.no_graph)
         fn = lambda: tr.step(u, seq, rsq, pos, prs, neg, nrs)
@@ -277,7 +335,7 @@ def explore(args, cfg, model, dev, rank):
         fn()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"workload": args.workload, "mode": "predict_top10" if args.predict else "train_step",
+    print(json.dumps({"workload": args.workload, "mode": "predict_top10" if args.predict else ("train_step_autograd_path" if args.autograd else "train_step"),
                       "kind": cfg["kind"], "sequences_per_s": B * args.steps / el, "ms_per_step": el / args.steps * 1e3,
                       "batch": B, "seq_len": L, "n_items": cfg["n_items"], "item_table": "bf16 shadow" if cfg.get("bf16_table") else "fp32",
                       "contract_line": False}), flush=True)
