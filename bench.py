@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-metric-parity", action="store_true", help="skip the end-to-end HR@10 run (profiling passes: keeps the "
+                    "per-kernel averages of the profile free of that run's small launches)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="exploration only; the contract line is C2")
     ap.add_argument("--deterministic", action="store_true", help="deterministic item-table scatter (sort + ordered sums) instead of float atomics")
     ap.add_argument("--autograd", action="store_true", help="exploration: time the module-level drop-in path (model(...) -> BCE -> "
@@ -289,7 +291,7 @@ def main():
                                       "achieved": step_bytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": step_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}},
         }
-        if world == 1:
+        if world == 1 and not args.no_metric_parity:
             try:
                 out["config"]["metric_parity"] = metric_parity()
             except Exception as e:          # never lose the throughput line to the side measurement
