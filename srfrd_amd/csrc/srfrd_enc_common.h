@@ -124,6 +124,21 @@ struct G2L {
       }
     }
   }
+  // [rows][cols] window of a row-major global matrix whose rows are `sld` floats apart (V2: cols, sld even)
+  __device__ __forceinline__ void load2d(const float* src, int rows, int cols, int sld, int nthr) {
+    const int cw = V2 ? cols >> 1 : cols, n = rows * cw;
+#pragma unroll
+    for (int u = 0; u < ITER; ++u) {
+      const int i = min(u * nthr + (int)threadIdx.x, n - 1);
+      const int t = i / cw, c = i - t * cw;
+      if constexpr (V2) {
+        const f32x2 w = *reinterpret_cast<const f32x2*>(src + (unsigned)(t * sld + 2 * c));
+        v[u][0] = w.x; v[u][1] = w.y;
+      } else {
+        v[u][0] = src[(unsigned)(t * sld + c)];
+      }
+    }
+  }
   __device__ __forceinline__ void store(lds_f* dst, int ld, int rows, int cols, int nthr, int base = 0) const {
     const int cw = V2 ? cols >> 1 : cols, n = rows * cw;
 #pragma unroll

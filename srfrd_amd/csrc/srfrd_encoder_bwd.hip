@@ -13,6 +13,7 @@ namespace srfrd {
 using namespace srfrd;
 
 extern "C" int srfrd_long_launch_bwd(const void* args, int grid, int threads, int variant, void* stream);   // srfrd_encoder_bwd_long.hip
+extern "C" int srfrd_bwd_slots_launch(const void* args, int grid, int L, int kind_variant, void* stream);    // srfrd_encoder_bwd_slots.hip
 
 extern "C" int srfrd_bwd_grid(int B) {
   if (B <= 0) return SRFRD_E_ARG;
@@ -43,6 +44,19 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table
   const Geom g = make_geom(L, lay->D);
   const int64_t lds = bwd_lds_floats(g, lay->n_blocks) * 4;
   const int grid = srfrd_bwd_grid(B);
+  if (lds > kLdsLimit && pos_ids && neg_ids && fused_bce && !d_hidden && !dbg && lay->D == 50 &&
+      getenv("SRFRD_NO_SLOTS") == nullptr && getenv("SRFRD_GENERIC") == nullptr) {
+    // fused training step of a long sequence: the slot-placed, query-chunked LDS-resident kernel where one is built
+    int kv = -1;
+    if (lay->kind == SRFRD_SASREC) kv = 0;
+    else if (lay->kind == SRFRD_SRFR && lay->d_item == 45) kv = 1;
+    else if (lay->kind == SRFRD_SRFRN && lay->d_item == 45) kv = 2;
+    else if (lay->kind >= SRFRD_SRFU_B && lay->d_item == 50) kv = 3;
+    if (kv >= 0) {
+      rc = srfrd_bwd_slots_launch(&a, grid, L, kv, stream);
+      if (rc != SRFRD_E_UNSUPPORTED) return rc;
+    }
+  }
   if (lds > kLdsLimit) {                       // long sequence: working set in the caller's global scratch
     const int64_t stride = (bwd_lds_floats(g, lay->n_blocks) + 2 * kSlack + 63) & ~63ll;
     if (!scratch || scratch_floats < stride * grid) return SRFRD_E_UNSUPPORTED;
