@@ -96,7 +96,7 @@ int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64_t* fwd_flo
 /* [host] floats of the forward's `save_aux` checkpoint buffer for (B, L): per block and sequence the FFN hidden
  * activation relu(drop(.)), the attention output P v, the scaled queries, the keys and the values (L, D each) and the
  * attention probabilities (L, LP = L rounded up to 16), the latter sign-coded with the attention-dropout mask (a
- * dropped entry is stored negated). */
+ * dropped entry is stored negated); sequence-major (all blocks of one sequence are contiguous). */
 int64_t srfrd_aux_floats(const srfrd_layout* lay, int B, int L);
 
 /* [host] number of persistent workgroups the backward launches for batch B (= rows of `grad_slabs`). */
@@ -131,8 +131,9 @@ int srfrd_pack_weights(const srfrd_layout* lay, const float* dense, float* packe
  *  dropout_p > 0 selects train mode; masks come from the counter hash of srfrd_rng.h keyed by
  *    (seed, site, seq_index0 + b, row, col); if seed_dev != NULL the seed is read from device memory
  *  hidden (B,L,d_out), pos_logits/neg_logits (B,L) outputs (logit pointers may be NULL iff the id pointer is)
- *  save_x (n_blocks+1, B, L, D): block inputs and the last block's output; save_h1 (n_blocks, B, L, D):
- *    post-attention residual; save_aux: srfrd_aux_floats() floats (see there); all three NULL for inference
+ *  save_x (B, n_blocks+1, L, D): block inputs and the last block's output; save_h1 (B, n_blocks, L, D):
+ *    post-attention residual; save_aux: srfrd_aux_floats() floats (see there); all three NULL for inference.
+ *    Sequence-major and opaque to the caller: written here, read back by srfrd_encoder_bwd
  *  loss_part (B,3) or NULL: per sequence {sum softplus(-pos), sum softplus(neg), count} over pos_ids != 0
  *  scratch / scratch_floats: srfrd_scratch_floats() floats of workspace (NULL / 0 when that is 0)
  *  dbg / dbg_seq: debug taps of one sequence (tests only; NULL otherwise)

@@ -44,21 +44,26 @@ struct EncArgs {
   int64_t dbg_slot;
 };
 
-// save_aux layout (srfrd_aux_floats): block i at i * B * aux_seq_floats; inside a block the planes
-// r, o, q, k, v [B][L][D] and Pm [B][L][LP]
+// Checkpoint layout: SEQUENCE-major.  Everything the backward reads back for sequence b is contiguous per buffer -
+// save_x: (nb + 1) blocks of [L][D] at b * (nb + 1) * L * D; save_h1: nb blocks at b * nb * L * D; save_aux
+// (srfrd_aux_floats): nb blocks of aux_seq_floats at b * nb * aux_seq_floats, each the planes r, o, q, k, v [L][D] and
+// Pm [L][LP].  (A block-major layout put the ten planes a workgroup touches per block 10 MB apart at BASELINE
+// configs[3]: every first access of a phase was a TLB miss on the sequence's critical path.)
 __host__ __device__ __forceinline__ int64_t aux_seq_floats(int L, int LP, int D) { return 5ll * L * D + (int64_t)L * LP; }
+__host__ __device__ __forceinline__ int64_t x_off(int i, int b, int nb, int L, int D) { return ((int64_t)b * (nb + 1) + i) * L * D; }
+__host__ __device__ __forceinline__ int64_t h1_off(int i, int b, int nb, int L, int D) { return ((int64_t)b * nb + i) * L * D; }
 struct AuxOff {
   int64_t r, o, q, k, v, p;
 };
-__host__ __device__ __forceinline__ AuxOff aux_off(int i, int b, int B, int L, int LP, int D) {
-  const int64_t blk = (int64_t)i * B * aux_seq_floats(L, LP, D), plane = (int64_t)B * L * D, seq = (int64_t)b * L * D;
+__host__ __device__ __forceinline__ AuxOff aux_off(int i, int b, int nb, int L, int LP, int D) {
+  const int64_t blk = ((int64_t)b * nb + i) * aux_seq_floats(L, LP, D), plane = (int64_t)L * D;
   AuxOff f;
-  f.r = blk + seq;
-  f.o = blk + plane + seq;
-  f.q = blk + 2 * plane + seq;
-  f.k = blk + 3 * plane + seq;
-  f.v = blk + 4 * plane + seq;
-  f.p = blk + 5 * plane + (int64_t)b * L * LP;
+  f.r = blk;
+  f.o = blk + plane;
+  f.q = blk + 2 * plane;
+  f.k = blk + 3 * plane;
+  f.v = blk + 4 * plane;
+  f.p = blk + 5 * plane;
   return f;
 }
 

@@ -44,7 +44,12 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table
   const Geom g = make_geom(L, lay->D);
   const int64_t lds = bwd_lds_floats(g, lay->n_blocks) * 4;
   const int grid = srfrd_bwd_grid(B);
-  if (lds > kLdsLimit && pos_ids && neg_ids && fused_bce && !d_hidden && !dbg && lay->D == 50 &&
+#ifdef SRFRD_STAMPS
+  const bool taps = false;                     // (diagnostic build: `dbg` receives the phase stamps)
+#else
+  const bool taps = dbg != nullptr;
+#endif
+  if (lds > kLdsLimit && pos_ids && neg_ids && fused_bce && !d_hidden && !taps && lay->D == 50 &&
       getenv("SRFRD_NO_SLOTS") == nullptr && getenv("SRFRD_GENERIC") == nullptr) {
     // fused training step of a long sequence: the slot-placed, query-chunked LDS-resident kernel where one is built
     int kv = -1;

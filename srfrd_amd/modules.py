@@ -245,8 +245,8 @@ class _SRFRDBase(nn.Module):
         hidden = torch.empty(B, L, lay.d_out, device=dev, dtype=torch.float32)
         pl = torch.empty(B, L, device=dev, dtype=torch.float32) if pos is not None else None
         nl = torch.empty(B, L, device=dev, dtype=torch.float32) if neg is not None else None
-        sx = torch.empty(lay.n_blocks + 1, B, L, lay.D, device=dev, dtype=torch.float32) if save else None
-        sh = torch.empty(lay.n_blocks, B, L, lay.D, device=dev, dtype=torch.float32) if save else None
+        sx = torch.empty(B, lay.n_blocks + 1, L, lay.D, device=dev, dtype=torch.float32) if save else None
+        sh = torch.empty(B, lay.n_blocks, L, lay.D, device=dev, dtype=torch.float32) if save else None
         sa = torch.empty(_lib.lib().srfrd_aux_floats(C.byref(lay), B, L), device=dev, dtype=torch.float32) if save else None
         packed = self.pack_weights()          # parameters may have been stepped since the last call
         scratch, n_scr = self._scratch_for(B, L, backward=False)

@@ -72,8 +72,8 @@ def _(params, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, model_k
     f = dict(device=input_ids.device, dtype=torch.float32)
     return [torch.empty(B, L, lay.d_out, **f), torch.empty(B, L, **f) if pos_ids is not None else torch.empty(0, **f),
             torch.empty(B, L, **f) if neg_ids is not None else torch.empty(0, **f),
-            torch.empty(lay.n_blocks + 1, B, L, lay.D, **f) if save else torch.empty(0, **f),
-            torch.empty(lay.n_blocks, B, L, lay.D, **f) if save else torch.empty(0, **f),
+            torch.empty(B, lay.n_blocks + 1, L, lay.D, **f) if save else torch.empty(0, **f),
+            torch.empty(B, lay.n_blocks, L, lay.D, **f) if save else torch.empty(0, **f),
             torch.empty(_lib.lib().srfrd_aux_floats(C.byref(lay), B, L), **f) if save else torch.empty(0, **f)]
 
 

@@ -98,8 +98,8 @@ class FusedTrainer:
         self.hidden = torch.empty(B, L, lay.d_out, **f32)
         self.pl = torch.empty(B, L, **f32)
         self.nl = torch.empty(B, L, **f32)
-        self.save_x = torch.empty(lay.n_blocks + 1, B, L, lay.D, **f32)
-        self.save_h1 = torch.empty(lay.n_blocks, B, L, lay.D, **f32)
+        self.save_x = torch.empty(B, lay.n_blocks + 1, L, lay.D, **f32)
+        self.save_h1 = torch.empty(B, lay.n_blocks, L, lay.D, **f32)
         self.save_aux = torch.empty(_lib.lib().srfrd_aux_floats(C.byref(lay), B, L), **f32)
         self.loss_part = torch.empty(B, 3, **f32)
         self.loss = torch.zeros(1, **f32)

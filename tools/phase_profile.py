@@ -23,7 +23,7 @@ def build():
     os.makedirs(tmp + "/include", exist_ok=True)
     for f in os.listdir(CSRC):
         open(f"{tmp}/srfrd_amd/csrc/{f}", "w").write(open(os.path.join(CSRC, f)).read())
-    for which in ("fwd", "bwd"):
+    for which in ("fwd", "bwd", "bwd_slots"):
         fname = f"srfrd_encoder_{which}_kernel.inc"
         out = _stamp_file(os.path.join(CSRC, fname), which, labels)
         open(f"{tmp}/srfrd_amd/csrc/{fname}", "w").write("\n".join(out))
@@ -115,8 +115,61 @@ def run():
                 print(f"  {i:3d} {float(mean[i]):9.0f} {100 * float(mean[i]) / tot:5.1f}%  {labels.get(f'{which}:{i}', '')}")
 
 
+def run_c4():
+    """seq_len 100 fused training step (BASELINE configs[3] geometry): the slot-placed backward, phase by phase"""
+    import ctypes as C
+    import json
+    import torch
+    os.environ["SRFRD_LIB_PATH"] = OUT
+    import srfrd_amd
+    from srfrd_amd import _lib
+    from srfrd_amd._lib import check, ptr
+    labels = json.load(open(OUT + ".labels.json"))
+    I, L, B, D = 200_000, 100, 512, 50
+    torch.manual_seed(0)
+    m = srfrd_amd.SASRec(I, L, D, 0.5, 2, 1, "cuda")
+    for _, p in m.named_parameters():
+        if p.dim() >= 2:
+            torch.nn.init.xavier_normal_(p.data)
+    m = m.cuda().train()
+    tr = srfrd_amd.FusedTrainer(m, B, L, use_graph=False)
+    tr.refresh()
+    tr.ids.copy_(srfrd_amd.synthetic_batch(I, L, B, seed=1, device="cuda", packed=True)[1])
+    tr._enqueue_fwd()
+    ids, fk, pfk, nfk, p, seed_dev, seq0 = tr._ids_of(0)
+    lay_t, tab = m._table_args()
+
+    def bwd(dbg):
+        check(_lib.lib().srfrd_encoder_bwd(C.byref(lay_t), tab, tr._dense_ptr(tr.flat), ptr(tr.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
+                                           ptr(pfk), ptr(ids[4]), ptr(nfk), B, L, p, 0, seed_dev, seq0, ptr(tr.hidden), ptr(tr.pl),
+                                           ptr(tr.nl), ptr(tr.save_x), ptr(tr.save_h1), ptr(tr.save_aux), None, None, None, 1,
+                                           ptr(tr.grad), None, ptr(tr.slabs), ptr(tr.scratch), tr.n_scratch,
+                                           ptr(dbg.view(torch.float32)), 0, tr._stream()), "srfrd_encoder_bwd")
+    dbg = torch.zeros(1024, 128, device="cuda", dtype=torch.int64)
+    dbg2 = torch.zeros(1024, 128, device="cuda", dtype=torch.int64)
+    bwd(dbg)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        bwd(dbg2)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"   stamped slots kernel: {e0.elapsed_time(e1) / 5 * 1000:.1f} us per launch")
+    d = dbg.cpu().double()
+    used = d[d.sum(1) > 0]
+    mean = used.mean(0)
+    tot = float(mean.sum())
+    print(f"== bwd_slots: {used.shape[0]} workgroups, {tot:.0f} ticks (100 MHz -> {tot / 100:.1f} us) per workgroup")
+    for i in range(128):
+        if mean[i] > 0:
+            print(f"  {i:3d} {float(mean[i]):9.0f} {100 * float(mean[i]) / tot:5.1f}%  {labels.get(f'bwd_slots:{i}', '')}")
+
+
 if __name__ == "__main__":
     if "--build" in sys.argv:
         build()
     if "--run" in sys.argv:
         run()
+    if "--c4" in sys.argv:
+        run_c4()
