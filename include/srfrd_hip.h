@@ -148,8 +148,16 @@ int srfrd_encoder_fwd(const srfrd_layout* lay, const void* item_table, const flo
                       float* scratch, int64_t scratch_floats,
                       float* dbg, int dbg_seq, void* stream);
 
+/* Inference forward for ranking: the encoder state of the LAST position only, hidden_last (B, d_out) - what the reference's
+ * predict() takes from log2feats (SRFR_model.py:668-681: `log_feats[:, -1, :]`).  Same arithmetic as srfrd_encoder_fwd in
+ * eval mode (row L - 1 of its `hidden`, bit for bit); the last block computes queries, attention rows, output projection
+ * and FFN for the one 16-row tile holding that position.  Feed it to srfrd_predict_logits / srfrd_logits_topk with L = 1. */
+int srfrd_encoder_fwd_last(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
+                           const int64_t* input_ids, const int64_t* fake_ids, int B, int L, float* hidden_last,
+                           float* scratch, int64_t scratch_floats, void* stream);
+
 /*
- * Fused backward of the above: LayerNorms are recomputed in LDS from save_x / save_h1; q / k / v, the FFN hidden
+ * Fused backward of srfrd_encoder_fwd: LayerNorms are recomputed in LDS from save_x / save_h1; q / k / v, the FFN hidden
  * activation, the attention probabilities (with their dropout mask) and the attention output are read back from
  * save_aux.  Replaces the
  * autograd pass behind `loss.backward()` (reference trainer.py:40).

@@ -45,6 +45,7 @@ SIGNATURES = {
     "srfrd_pack_weights": (_i, [_LP, _P, _P, _P, _d, _d, _d, _P]),
     "srfrd_encoder_fwd": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
                                _P, _P, _P, _P, _P, _P, _P, _P, _i64, _P, _i, _P]),
+    "srfrd_encoder_fwd_last": (_i, [_LP, _P, _P, _P, _P, _P, _i, _i, _P, _P, _i64, _P]),
     "srfrd_encoder_bwd": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, _P, _i64, _P, _i, _P]),
     "srfrd_table_reduce": (_i, [_P, _P, _P, _i64, _i, _P, _P]),

@@ -637,11 +637,11 @@ constexpr int kSMJ = 128 / kRL;     // elements per lane: rows up to 128 keys
 // diagonal).  The backward pass reads them back instead of recomputing q k^T, the softmax and the mask hash.
 template <bool MASKED>
 __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld, int LP, const DropSite& ds,
-                                             lds_f* S_masked = nullptr, float* gsave = nullptr) {
+                                             lds_f* S_masked = nullptr, float* gsave = nullptr, int row0 = 0) {
   const int q = threadIdx.x & (kRL - 1), rpp = (nw << 6) / kRL;
   const int nj = LP / kRL;                       // elements per lane (LP is a multiple of 16)
   if (nj > kSMJ) {                              // rows longer than 4 * kSMJ keys: streaming three-pass form
-    for (int r = threadIdx.x / kRL; r < rows; r += rpp) {
+    for (int r = row0 + threadIdx.x / kRL; r < rows; r += rpp) {
       lds_f* row = S + r * sld;
       float m = -INFINITY;
       for (int j = q; j <= r; j += kRL) m = fmaxf(m, row[j]);
@@ -667,7 +667,7 @@ __device__ __forceinline__ void softmax_rows(int nw, lds_f* S, int rows, int sld
     }
     return;
   }
-  for (int r = threadIdx.x / kRL; r < rows; r += rpp) {
+  for (int r = row0 + threadIdx.x / kRL; r < rows; r += rpp) {
     lds_f* row = S + r * sld;
     float x[kSMJ];
     float m = -INFINITY;

@@ -31,6 +31,7 @@ struct EncArgs {
   // backward inputs / outputs
   const float *c_hidden, *c_pl, *c_nl, *c_save_x, *c_save_h1, *c_save_aux, *d_hidden, *d_pos, *d_neg;
   int fused_bce;
+  int last_only;       // forward, inference: only the LAST position's hidden state is wanted (hidden is (B, d_out))
   float *grad_table, *grad_slabs;
   float* contrib;      // deterministic table scatter: (3, B, L, d_item) row contributions instead of float atomics (or NULL)
   // SRFRD_BUF_GLOBAL build only: per-workgroup working-set scratch (floats) in global memory

@@ -98,14 +98,15 @@ extern "C" int srfrd_debug_shape(const srfrd_layout* lay, int L, int64_t* slot_f
   return 0;
 }
 
-extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
-                                 const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
-                                 const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
-                                 double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
-                                 float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
-                                 float* save_aux, float* loss_part, float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq,
-                                 void* stream) {
+static int encoder_fwd_impl(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
+                            const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
+                            const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
+                            double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
+                            float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
+                            float* save_aux, float* loss_part, float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq,
+                            int last_only, void* stream) {
   EncArgs a = {};
+  a.last_only = last_only;
   int rc = fill_args(a, lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
                      dropout_p, seed, seed_dev, seq_index0);
   if (rc) return rc;
@@ -156,6 +157,26 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const void* item_table
   if (spec && threads == 512 && g.LP == 32) return launch_enc(encoder_fwd_kernel<50, 32, 8>, grid, threads, lds, stream, a);
   if (spec && threads == 256 && g.LP == 64) return launch_enc(encoder_fwd_kernel<50, 64, 4>, grid, threads, lds, stream, a);
   return launch_enc(encoder_fwd_kernel<0, 0, 0>, grid, threads, lds, stream, a);
+}
+
+extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
+                                 const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
+                                 const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
+                                 double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
+                                 float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
+                                 float* save_aux, float* loss_part, float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq,
+                                 void* stream) {
+  return encoder_fwd_impl(lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L, dropout_p,
+                          seed, seed_dev, seq_index0, hidden, pos_logits, neg_logits, save_x, save_h1, save_aux, loss_part, scratch,
+                          scratch_floats, dbg, dbg_seq, 0, stream);
+}
+
+extern "C" int srfrd_encoder_fwd_last(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
+                                      const int64_t* input_ids, const int64_t* fake_ids, int B, int L, float* hidden_last,
+                                      float* scratch, int64_t scratch_floats, void* stream) {
+  return encoder_fwd_impl(lay, item_table, dense, packed, input_ids, fake_ids, nullptr, nullptr, nullptr, nullptr, B, L, 0.0, 0,
+                          nullptr, 0, hidden_last, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scratch, scratch_floats,
+                          nullptr, 0, 1, stream);
 }
 
 extern "C" int srfrd_layout_init(srfrd_layout* lay, int kind, int n_items, int max_len, int d_item, int d_fake,

@@ -258,6 +258,19 @@ class _SRFRDBase(nn.Module):
             int(dbg_seq), _stream()), "srfrd_encoder_fwd")
         return {"hidden": hidden, "pos_logits": pl, "neg_logits": nl, "save_x": sx, "save_h1": sh, "save_aux": sa}
 
+    def _launch_fwd_last(self, inp, fk):
+        """Eval-mode encoder state of the last position only, (B, 1, d_out): what predict() / topk() rank with."""
+        lay, flat = self.layout, self._flat
+        B, L = inp.shape
+        hidden = torch.empty(B, 1, lay.d_out, device=inp.device, dtype=torch.float32)
+        packed = self.pack_weights()
+        scratch, n_scr = self._scratch_for(B, L, backward=False)
+        lay_t, tab = self._table_args()
+        check(_lib.lib().srfrd_encoder_fwd_last(
+            C.byref(lay_t), tab, C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad), ptr(packed), ptr(inp), ptr(fk), B, L,
+            ptr(hidden), ptr(scratch), n_scr, _stream()), "srfrd_encoder_fwd_last")
+        return hidden
+
     def _launch_bwd(self, inp, fk, pos, pfk, neg, nfk, dropout_p, seed, out, d_hidden, d_pl, d_nl, seq0=0,
                     dbg=None, dbg_seq=0):
         lay, flat = self.layout, self._flat
@@ -352,8 +365,8 @@ class _SRFRDBase(nn.Module):
         returns (I_c,) for a single sequence, else (B, I_c) - the reference's ``.squeeze()`` behaviour."""
         with torch.no_grad():
             ids = self._prep(input_ids, fake_ids, None, None, None, None)
-            out = self._launch_fwd(*ids, 0.0, 0, save=False)
-        logits = self.candidate_logits(out["hidden"], ids[1], label)
+            hidden = self._launch_fwd_last(ids[0], ids[1])
+        logits = self.candidate_logits(hidden, ids[1], label)
         return logits.squeeze()
 
     def candidate_logits(self, hidden, fake_ids, cand):
@@ -377,10 +390,8 @@ class _SRFRDBase(nn.Module):
         """Full-catalog ranking: (indices int64 (B,k), scores (B,k)); the (B, I) logits never reach HBM."""
         with torch.no_grad():
             ids = self._prep(input_ids, fake_ids, None, None, None, None)
-            out = self._launch_fwd(*ids, 0.0, 0, save=False)
+            hidden = self._launch_fwd_last(ids[0], ids[1])
         lay = self.layout
-        hidden = out["hidden"]
-        B, L = hidden.shape[0], hidden.shape[1]
         lo, hi = item_range if item_range is not None else (0, lay.n_items + 1)
         ulab = self.user_labels(ids[1]) if self._kind == "SRFRN" else None
         idx, val = torch.ops.srfrd.logits_topk(hidden, ulab, ops.register_model(self), lo, hi, k, bool(exclude_pad))

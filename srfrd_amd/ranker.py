@@ -66,8 +66,7 @@ class ShardedRanker:
         """-> (indices int64 (B,k), scores (B,k)) of this rank's users over the WHOLE catalog."""
         m = self.model
         ids = m._prep(input_ids, fake_ids, None, None, None, None)
-        hidden = m._launch_fwd(*ids, 0.0, 0, save=False)["hidden"]
-        h_last = hidden[:, -1, :].contiguous()                       # (B, d_out)
+        h_last = m._launch_fwd_last(ids[0], ids[1])[:, 0, :]          # (B, d_out)
         ulab = m.user_labels(ids[1]) if m._kind == "SRFRN" else None
         B = h_last.shape[0]
         if not self.dist_on:

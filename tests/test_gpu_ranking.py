@@ -169,3 +169,32 @@ def test_c2_untrained_hit_rate_is_chance(c2):
     assert 0.04 < hr < 0.18                       # 10 / 101 for a random ranker (512 users)
     idx, val = m.topk(u, seq, rsq, k=10)
     assert idx.shape == (512, 10) and bool((val[:, :-1] >= val[:, 1:]).all()) and bool((idx >= 1).all())
+
+
+@pytest.mark.parametrize("kind,L", [("SASRec", 50), ("SRFR", 50), ("SRFRN", 20), ("SRFU_F", 37), ("SASRec", 100), ("SRFRN", 200)])
+def test_last_position_forward_equals_last_row_of_full_forward(kind, L):
+    """srfrd_encoder_fwd_last (what predict() / topk() rank with): the last block works on the one 16-row tile that holds
+    position L - 1 - bit for bit row L - 1 of the full eval-mode forward, for every kind, on the LDS-resident builds
+    (L <= 112) and the global-scratch build (L = 200), with left-padded and full sequences in the batch."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, random_sd
+    I, B = 300, 9
+    if kind == "SASRec":
+        cfg = O.Cfg(kind, I, L, 50)
+    elif kind in ("SRFR", "SRFRN"):
+        cfg = O.Cfg(kind, I, L, 45, d_fake=5)
+    else:
+        cfg = O.Cfg(kind, I, L, 50, n_labels=L + 1)          # SRFU_F: the label is the number of fake reviews
+    sd = random_sd(cfg, 4)
+    model = build_model(cfg, sd).eval()
+    batch = srfrd_amd.synthetic_batch(I, L, B, seed=11, device="cpu")
+    seq, rsq = cuda(batch[1], batch[2])
+    seq[0] = torch.randint(1, I + 1, (L,), device=seq.device)          # one sequence without padding
+    with torch.no_grad():
+        ids = model._prep(seq, rsq, None, None, None, None)
+        full = model._launch_fwd(*ids, 0.0, 0, save=False)["hidden"]
+        last = model._launch_fwd_last(ids[0], ids[1])
+    assert last.shape == (B, 1, cfg.d_out)
+    assert torch.equal(last[:, 0], full[:, -1])
+    ho, _, _ = O.forward(cfg, sd, seq.cpu(), rsq.cpu(), None, None, None, None)
+    assert float((last[:, 0].cpu() - ho[:, -1]).abs().max()) < 1e-4
