@@ -281,6 +281,178 @@ __device__ __forceinline__ void topk_stream(const TopkArgs& a, BEG&& begin, ELEM
   }
 }
 
+// ---- bf16 item table (srfrd_layout::table_bf16): the threshold passes on the bf16 matrix cores --------------------------
+// The table rows are exact bf16; a hidden state splits EXACTLY into three bf16 terms (h = h1 + h2 + h3: 3 x 8 significand
+// bits), so logit = sum_k (h1 + h2 + h3)_k e_k is three v_mfma_f32_16x16x32_bf16 products per 32-deep k-step with exact
+// products and fp32 accumulation - fp32-grade logits at 6 x 16 cycles per 16 x 16 tile instead of 13 x 32 on the fp32 form.
+// A wave keeps the fragments of its four 16-item row tiles in REGISTERS for the whole launch (loaded straight from the
+// table: the items never pass through LDS) and streams the user tiles past them; LDS holds only the split hidden rows of
+// the current and the next user tile.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifdef SRFRD_BUF_GLOBAL
+typedef uint16_t lds_u16;
+typedef bf16x8 lds_bf16x8;
+#else
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+#endif
+constexpr int kTilesW = 4;                      // item row tiles per wave
+constexpr int kChunk16 = 8 * kTilesW * 16;      // items per workgroup (8 waves): 512
+constexpr int kHS = 72;                         // bf16 row stride of a hidden tile in LDS (64 + 8: rows 144 B apart)
+constexpr int kStream16Lds = 2 * 3 * 16 * kHS * 2 + (32 + 8 * 16) * 4;
+
+template <class BEG, class ELEM, class END>
+__device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, ELEM&& elem, END&& end) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lq = lane >> 4;
+  const srfrd_layout& ly = a.ly;
+  const int di = ly.d_item, dout = ly.d_out, D = ly.D;
+  const bool srfrn = ly.kind == SRFRD_SRFRN;
+  lds_u16* sH = (lds_u16*)smem;                               // [2][3][16][kHS]
+  lds_f* sF = (lds_f*)(sH + 2 * 3 * 16 * kHS);                // [2][16]
+  lds_f* sM = sF + 32;                                        // scratch of the end() step: [nw][16]
+  const int chunk = blockIdx.x / a.user_splits, split = blockIdx.x - chunk * a.user_splits;
+  const int64_t i0 = a.item_lo + (int64_t)chunk * kChunk16;
+  for (int idx = tid; idx < 2 * 3 * 16 * kHS; idx += nthr) sH[idx] = 0;      // k-padding columns stay zero
+  // item fragments: lane (li, lq) of row tile j holds item i0 + 16 (4 wave + j) + li, k = 32 ks + 8 lq + 0..7
+  const uint16_t* tab = (const uint16_t*)a.table;
+  bf16x8 af[kTilesW][2];
+#pragma unroll
+  for (int j = 0; j < kTilesW; ++j) {
+    const int64_t item = i0 + ((wave * kTilesW + j) << 4) + li;
+    const bool valid = item < a.item_hi;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      union { bf16x8 v; uint32_t w[4]; uint16_t h[8]; } u;
+      u.w[0] = u.w[1] = u.w[2] = u.w[3] = 0;
+      const int k0 = 32 * ks + 8 * lq;
+      if (valid) {
+        if ((di & 1) == 0) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            if (k0 + 2 * p < di) u.w[p] = *reinterpret_cast<const uint32_t*>(tab + item * di + k0 + 2 * p);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (k0 + e < di) u.h[e] = tab[item * di + k0 + e];
+        }
+      }
+      af[j][ks] = u.v;
+    }
+  }
+  constexpr int HIT = 2;                 // 16 x d_item hidden elements over 512 threads
+  float hv[HIT];
+  float fside = 0.f;
+  auto fetch = [&](int u0) {
+#pragma unroll
+    for (int u = 0; u < HIT; ++u) {
+      const int i = min(u * nthr + tid, 16 * di - 1);
+      const int r = i / di, c = i - r * di;
+      hv[u] = a.hidden[((int64_t)min(u0 + r, a.B - 1) * a.L + (a.L - 1)) * dout + c];
+    }
+    if (srfrn && tid < 16) {
+      float sacc = 0.f;
+      if (u0 + tid < a.B) {
+        const int lab = clamp_id(a.user_label[u0 + tid], 2);
+        for (int c = di; c < D; ++c)
+          sacc += a.hidden[((int64_t)(u0 + tid) * a.L + (a.L - 1)) * dout + c] * a.dense[ly.off_side + lab * ly.d_fake + (c - di)];
+      }
+      fside = sacc;
+    }
+  };
+  auto put = [&](int u0, int buf) {
+#pragma unroll
+    for (int u = 0; u < HIT; ++u) {
+      const int i = u * nthr + tid;
+      if (i < 16 * di) {
+        const int r = i / di, c = i - r * di;
+        const float x = u0 + r < a.B ? hv[u] : 0.f;
+        const uint16_t h1 = f32_to_bf16(x);
+        const float r1 = x - bf16_to_f32(h1);
+        const uint16_t h2 = f32_to_bf16(r1);
+        const float r2 = r1 - bf16_to_f32(h2);
+        const uint16_t h3 = f32_to_bf16(r2);
+        sH[((buf * 3 + 0) * 16 + r) * kHS + c] = h1;
+        sH[((buf * 3 + 1) * 16 + r) * kHS + c] = h2;
+        sH[((buf * 3 + 2) * 16 + r) * kHS + c] = h3;
+      }
+    }
+    if (srfrn && tid < 16) sF[buf * 16 + tid] = fside;
+  };
+  const int ustep = a.user_splits * 16;
+  int u0 = split * 16, cur = 0;
+  __syncthreads();                       // (the zero fill above)
+  if (u0 < a.B) { fetch(u0); put(u0, 0); }
+  __syncthreads();
+  for (; u0 < a.B; u0 += ustep) {
+    const bool more = u0 + ustep < a.B;
+    if (more) fetch(u0 + ustep);
+    begin(u0);
+    const lds_f* fcur = sF + cur * 16;
+    bf16x8 bfr[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        bfr[t][ks] = *reinterpret_cast<const lds_bf16x8*>(sH + ((cur * 3 + t) * 16 + li) * kHS + 32 * ks + 8 * lq);
+    const float fs = srfrn ? fcur[li] : 0.f;
+#pragma unroll
+    for (int j = 0; j < kTilesW; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 2; t >= 0; --t)                     // smallest term first
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][ks], bfr[t][ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t item = i0 + ((wave * kTilesW + j) << 4) + (lq << 2) + e;
+        const bool ok = item < a.item_hi && !(a.exclude_pad && item == 0);
+        elem(u0, li, item, ok ? acc[e] + fs : -INFINITY);
+      }
+    }
+    if (more) put(u0 + ustep, cur ^ 1);
+    end(u0, chunk, sM);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+__global__ void __launch_bounds__(512, 2) topk_max16_kernel(const TopkArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float m = -INFINITY;
+  topk_stream16(a,
+      [&](int) { m = -INFINITY; },
+      [&](int, int, int64_t, float v) { m = fmaxf(m, v); },
+      [&](int u0, int chunk, lds_f* sM) {
+        float mm = fmaxf(m, __shfl_xor(m, 16, 64));
+        mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
+        if (lane < 16) sM[wave * 16 + lane] = mm;
+        __syncthreads();
+        if (threadIdx.x < 16 && u0 + (int)threadIdx.x < a.B) {
+          float t = -INFINITY;
+          for (int w = 0; w < nw; ++w) t = fmaxf(t, sM[w * 16 + threadIdx.x]);
+          a.cmax[(int64_t)(u0 + threadIdx.x) * a.n_chunks + chunk] = t;
+        }
+      });
+}
+
+__global__ void __launch_bounds__(512, 2) topk_collect16_kernel(const TopkArgs a) {
+  const int li = threadIdx.x & 15;
+  float tau = INFINITY;
+  topk_stream16(a,
+      [&](int u0) { tau = u0 + li < a.B ? a.tau[u0 + li] : INFINITY; },
+      [&](int u0, int c, int64_t item, float v) {
+        if (v != -INFINITY && v >= tau) {
+          const int b = u0 + c;
+          const int slot = atomicAdd(&a.ccnt[b], 1);
+          if (slot < kCandMax) a.cand[(int64_t)b * kCandMax + slot] = Cand{v, (int32_t)item};
+          else a.ccnt[a.B] = 1;
+        }
+      },
+      [&](int, int, lds_f*) {});
+}
+
 __global__ void __launch_bounds__(512) topk_max_kernel(const TopkArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   float m = -INFINITY;                     // this lane's user column (lane & 15) over the row tiles of its wave
@@ -636,9 +808,29 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const void* item_table
   }
   a.user_splits = splits;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(topk_max_kernel, dim3(n_chunks * splits), dim3(512), lds_stream, st, a);
-  hipLaunchKernelGGL(topk_tau_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(topk_collect_kernel, dim3(n_chunks * splits), dim3(512), lds_stream, st, a);
+  if (lay->table_bf16 && lay->d_item <= 64 && getenv("SRFRD_TOPK_FP32") == nullptr) {
+    // bf16 table: the two threshold passes on the bf16 matrix cores (512-item chunks held in registers); the chunk maxima
+    // array is walked with the smaller chunk count, everything else (tau, candidate lists, selection, the armed exhaustive
+    // path with its own 256-item chunks) is shared
+    TopkArgs h = a;
+    h.n_chunks = (int)((item_hi - item_lo + kChunk16 - 1) / kChunk16);
+    int sp16 = 1;
+    double best16 = 1e30;
+    for (int sp = 1; sp <= user_tiles && sp <= 64; ++sp) {
+      const int64_t wgs = (int64_t)h.n_chunks * sp;
+      const double rounds = (double)((wgs + 511) / 512);
+      const double cost = rounds * (3.0 + (double)((user_tiles + sp - 1) / sp));
+      if (cost < best16) { best16 = cost; sp16 = sp; }
+    }
+    h.user_splits = sp16;
+    hipLaunchKernelGGL(topk_max16_kernel, dim3(h.n_chunks * sp16), dim3(512), kStream16Lds, st, h);
+    hipLaunchKernelGGL(topk_tau_kernel, dim3((B + 3) / 4), dim3(256), 0, st, h);
+    hipLaunchKernelGGL(topk_collect16_kernel, dim3(h.n_chunks * sp16), dim3(512), kStream16Lds, st, h);
+  } else {
+    hipLaunchKernelGGL(topk_max_kernel, dim3(n_chunks * splits), dim3(512), lds_stream, st, a);
+    hipLaunchKernelGGL(topk_tau_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(topk_collect_kernel, dim3(n_chunks * splits), dim3(512), lds_stream, st, a);
+  }
   hipLaunchKernelGGL(topk_select_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a, topk_idx, topk_val);
   // exhaustive path, armed only if a candidate list overflowed (device-side flag: no host synchronisation)
   hipLaunchKernelGGL(topk_stage1_kernel, dim3(n_chunks), dim3(256), lds, st, *lay, item_table, dense, hidden, B, L, item_lo,
