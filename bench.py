@@ -310,7 +310,8 @@ def explore(args, cfg, model, dev, rank):
     B, L = cfg["batch"], cfg["seq_len"]
     u, seq, rsq, pos, prs, neg, nrs = srfrd_amd.synthetic_batch(cfg["n_items"], L, B, seed=1, rank=rank, device=dev)
     if cfg.get("bf16_table"):
-        model.use_bf16_table()
+        # ranking with frozen weights (serving): the bf16 shadow is derived once, not on every call; training keeps it current itself
+        model.use_bf16_table(auto_refresh=not args.predict)
     if args.predict:
         model.eval()
         fn = lambda: model.topk(u, seq, rsq, k=10)

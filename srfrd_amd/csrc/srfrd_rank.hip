@@ -93,6 +93,7 @@ struct TopkArgs {
   const float *dense, *hidden;
   const int64_t* user_label;
   int B, L, exclude_pad, k, n_chunks, user_splits;
+  int crows, wg_per_group;      // bf16 streams: item rows per chunk (256 / 512), persistent workgroups per user group
   int64_t item_lo, item_hi;
   float* cmax;          // (B, n_chunks)
   float* tau;           // (B)
@@ -285,172 +286,207 @@ __device__ __forceinline__ void topk_stream(const TopkArgs& a, BEG&& begin, ELEM
 // The table rows are exact bf16; a hidden state splits EXACTLY into three bf16 terms (h = h1 + h2 + h3: 3 x 8 significand
 // bits), so logit = sum_k (h1 + h2 + h3)_k e_k is three v_mfma_f32_16x16x32_bf16 products per 32-deep k-step with exact
 // products and fp32 accumulation - fp32-grade logits at 6 x 16 cycles per 16 x 16 tile instead of 13 x 32 on the fp32 form.
-// A wave keeps the fragments of its four 16-item row tiles in REGISTERS for the whole launch (loaded straight from the
-// table: the items never pass through LDS) and streams the user tiles past them; LDS holds only the split hidden rows of
-// the current and the next user tile.
+//
+// Shape of the launch: the USERS live in registers, the ITEMS stream past them.  A 16-wave workgroup (one per CU,
+// persistent) serves a group of 16 x 16 x NU users: wave w keeps the split hidden-state fragments of user tiles w, w + 16
+// (NU x 24 registers) for the whole launch, so nothing about a user is ever staged again.  The workgroup walks its share
+// of the item chunks (256 or 512 rows): a chunk is copied table -> registers -> LDS (rows padded to 144 B) while the
+// previous one is being multiplied (two buffers, ONE barrier per chunk), and every wave reads every item tile of the chunk
+// from LDS (two ds_read_b128 feed 6 NU MFMAs).  With users on the accumulator column, the per-(user, chunk) maximum and
+// the candidate test are wave-local: no cross-wave reduction, no atomics in the maximum pass.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#ifdef SRFRD_BUF_GLOBAL
-typedef uint16_t lds_u16;
-typedef bf16x8 lds_bf16x8;
-#else
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
-#endif
-constexpr int kTilesW = 4;                      // item row tiles per wave
-constexpr int kChunk16 = 8 * kTilesW * 16;      // items per workgroup (8 waves): 512
-constexpr int kHS = 72;                         // bf16 row stride of a hidden tile in LDS (64 + 8: rows 144 B apart)
-constexpr int kStream16Lds = 2 * 3 * 16 * kHS * 2 + (32 + 8 * 16) * 4;
+constexpr int kWaves16 = 16;                    // waves per workgroup of the bf16 streams
+constexpr int kChunk16 = 512;                   // most item rows of a chunk
+constexpr int kHS = 72;                         // bf16 row stride of an item row in LDS (64 + 8: rows 144 B apart)
+constexpr int kStream16Lds = 2 * kChunk16 * kHS * 2;
 
-template <class BEG, class ELEM, class END>
+// begin(ut, user0) once per owned user tile; elem(ut, user0, item0, v) with the lane's four consecutive items of user user0 + li;
+// end(ut, user0, chunk) once per (user tile, chunk)
+template <int NU, class BEG, class ELEM, class END>
 __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, ELEM&& elem, END&& end) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int tid = threadIdx.x, nthr = kWaves16 * 64;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lq = lane >> 4;
   const srfrd_layout& ly = a.ly;
   const int di = ly.d_item, dout = ly.d_out, D = ly.D;
   const bool srfrn = ly.kind == SRFRD_SRFRN;
-  lds_u16* sH = (lds_u16*)smem;                               // [2][3][16][kHS]
-  lds_f* sF = (lds_f*)(sH + 2 * 3 * 16 * kHS);                // [2][16]
-  lds_f* sM = sF + 32;                                        // scratch of the end() step: [nw][16]
-  const int chunk = blockIdx.x / a.user_splits, split = blockIdx.x - chunk * a.user_splits;
-  const int64_t i0 = a.item_lo + (int64_t)chunk * kChunk16;
-  for (int idx = tid; idx < 2 * 3 * 16 * kHS; idx += nthr) sH[idx] = 0;      // k-padding columns stay zero
-  // item fragments: lane (li, lq) of row tile j holds item i0 + 16 (4 wave + j) + li, k = 32 ks + 8 lq + 0..7
-  const uint16_t* tab = (const uint16_t*)a.table;
-  bf16x8 af[kTilesW][2];
+  lds_u16* sE = (lds_u16*)smem;                               // [2][kChunk16][kHS]
+  const int group = blockIdx.x / a.wg_per_group, pw = blockIdx.x - group * a.wg_per_group;
+  for (int idx = tid; idx < 2 * kChunk16 * kHS / 2; idx += nthr) ((lds_u32*)sE)[idx] = 0;      // k-padding columns stay zero
+  // ---- this wave's users: split hidden fragments (lane (li, lq): user tile row li, k = 32 ks + 8 lq + 0..7) and side terms
+  bf16x8 bfr[NU][3][2];
+  float fs[NU];
+  int user0[NU];
 #pragma unroll
-  for (int j = 0; j < kTilesW; ++j) {
-    const int64_t item = i0 + ((wave * kTilesW + j) << 4) + li;
-    const bool valid = item < a.item_hi;
+  for (int n = 0; n < NU; ++n) {
+    user0[n] = (group * kWaves16 * NU + n * kWaves16 + wave) << 4;
+    const int ub = min(user0[n] + li, a.B - 1);
+    const float* hrow = a.hidden + ((int64_t)ub * a.L + (a.L - 1)) * dout;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      union { bf16x8 v; uint32_t w[4]; uint16_t h[8]; } u;
-      u.w[0] = u.w[1] = u.w[2] = u.w[3] = 0;
-      const int k0 = 32 * ks + 8 * lq;
-      if (valid) {
-        if ((di & 1) == 0) {
+      union { bf16x8 v; uint16_t h[8]; } t1, t2, t3;
+      float xv[8];
 #pragma unroll
-          for (int p = 0; p < 4; ++p)
-            if (k0 + 2 * p < di) u.w[p] = *reinterpret_cast<const uint32_t*>(tab + item * di + k0 + 2 * p);
-        } else {
+      for (int e = 0; e < 8; ++e) xv[e] = hrow[min(32 * ks + 8 * lq + e, di - 1)];      // (clamped, unconditional: one round trip)
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (k0 + e < di) u.h[e] = tab[item * di + k0 + e];
-        }
-      }
-      af[j][ks] = u.v;
-    }
-  }
-  constexpr int HIT = 2;                 // 16 x d_item hidden elements over 512 threads
-  float hv[HIT];
-  float fside = 0.f;
-  auto fetch = [&](int u0) {
-#pragma unroll
-    for (int u = 0; u < HIT; ++u) {
-      const int i = min(u * nthr + tid, 16 * di - 1);
-      const int r = i / di, c = i - r * di;
-      hv[u] = a.hidden[((int64_t)min(u0 + r, a.B - 1) * a.L + (a.L - 1)) * dout + c];
-    }
-    if (srfrn && tid < 16) {
-      float sacc = 0.f;
-      if (u0 + tid < a.B) {
-        const int lab = clamp_id(a.user_label[u0 + tid], 2);
-        for (int c = di; c < D; ++c)
-          sacc += a.hidden[((int64_t)(u0 + tid) * a.L + (a.L - 1)) * dout + c] * a.dense[ly.off_side + lab * ly.d_fake + (c - di)];
-      }
-      fside = sacc;
-    }
-  };
-  auto put = [&](int u0, int buf) {
-#pragma unroll
-    for (int u = 0; u < HIT; ++u) {
-      const int i = u * nthr + tid;
-      if (i < 16 * di) {
-        const int r = i / di, c = i - r * di;
-        const float x = u0 + r < a.B ? hv[u] : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        const int k = 32 * ks + 8 * lq + e;
+        const float x = k < di ? xv[e] : 0.f;
         const uint16_t h1 = f32_to_bf16(x);
         const float r1 = x - bf16_to_f32(h1);
         const uint16_t h2 = f32_to_bf16(r1);
         const float r2 = r1 - bf16_to_f32(h2);
-        const uint16_t h3 = f32_to_bf16(r2);
-        sH[((buf * 3 + 0) * 16 + r) * kHS + c] = h1;
-        sH[((buf * 3 + 1) * 16 + r) * kHS + c] = h2;
-        sH[((buf * 3 + 2) * 16 + r) * kHS + c] = h3;
+        t1.h[e] = h1; t2.h[e] = h2; t3.h[e] = f32_to_bf16(r2);
       }
+      bfr[n][0][ks] = t1.v; bfr[n][1][ks] = t2.v; bfr[n][2][ks] = t3.v;
     }
-    if (srfrn && tid < 16) sF[buf * 16 + tid] = fside;
+    float sacc = 0.f;
+    if (srfrn) {
+      const int lab = clamp_id(a.user_label[ub], 2);
+      for (int c = di; c < D; ++c) sacc += hrow[c] * a.dense[ly.off_side + lab * ly.d_fake + (c - di)];
+    }
+    fs[n] = sacc;
+    begin(n, user0[n]);
+  }
+  // ---- item chunks: table -> registers -> LDS; thread t owns dwords t, t + nthr, ... of the chunk's [crows][d_item / 2]
+  const uint16_t* tab = (const uint16_t*)a.table;
+  const bool dw = (di & 1) == 0;                       // rows are whole dwords (d_item even): 4-byte copies
+  const int rw = dw ? di >> 1 : di;                    // copy elements per row
+  constexpr int SIT = 13;                              // 512 rows x 25 dwords over 1024 threads
+  uint32_t sv[SIT];
+  // (the thread index is laundered at every use: its per-slot row / column split is cheap to redo and would otherwise
+  // sit in 26 registers for the whole launch)
+  auto fetch = [&](int chunk) {
+    const int64_t i0 = a.item_lo + (int64_t)chunk * a.crows;
+    const int nrow = (int)((a.item_hi - i0) < a.crows ? (a.item_hi - i0) : a.crows);
+    const int n = nrow * rw;
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    if (dw) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(tab + i0 * di);
+#pragma unroll
+      for (int u = 0; u < SIT; ++u) sv[u] = src[min(u * nthr + tl, n - 1)];
+    } else {
+      const uint16_t* src = tab + i0 * di;
+#pragma unroll
+      for (int u = 0; u < SIT; ++u) sv[u] = (uint32_t)src[min(u * nthr + tl, n - 1)];
+    }
   };
-  const int ustep = a.user_splits * 16;
-  int u0 = split * 16, cur = 0;
-  __syncthreads();                       // (the zero fill above)
-  if (u0 < a.B) { fetch(u0); put(u0, 0); }
-  __syncthreads();
-  for (; u0 < a.B; u0 += ustep) {
-    const bool more = u0 + ustep < a.B;
-    if (more) fetch(u0 + ustep);
-    begin(u0);
-    const lds_f* fcur = sF + cur * 16;
-    bf16x8 bfr[3][2];
+  auto put = [&](int chunk, int buf) {
+    const int64_t i0 = a.item_lo + (int64_t)chunk * a.crows;
+    const int nrow = (int)((a.item_hi - i0) < a.crows ? (a.item_hi - i0) : a.crows);
+    const int n = nrow * rw;
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    if (dw) {
+      lds_u32* dst = (lds_u32*)sE + buf * kChunk16 * (kHS / 2);
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+      for (int u = 0; u < SIT; ++u) {
+        const int i = u * nthr + tl;
+        const int r = i / rw, c = i - r * rw;
+        if (i < n) dst[r * (kHS / 2) + c] = sv[u];
+      }
+    } else {
+      lds_u16* dst = sE + buf * kChunk16 * kHS;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        bfr[t][ks] = *reinterpret_cast<const lds_bf16x8*>(sH + ((cur * 3 + t) * 16 + li) * kHS + 32 * ks + 8 * lq);
-    const float fs = srfrn ? fcur[li] : 0.f;
-#pragma unroll
-    for (int j = 0; j < kTilesW; ++j) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 2; t >= 0; --t)                     // smallest term first
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][ks], bfr[t][ks], acc, 0, 0, 0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int64_t item = i0 + ((wave * kTilesW + j) << 4) + (lq << 2) + e;
-        const bool ok = item < a.item_hi && !(a.exclude_pad && item == 0);
-        elem(u0, li, item, ok ? acc[e] + fs : -INFINITY);
+      for (int u = 0; u < SIT; ++u) {
+        const int i = u * nthr + tl;
+        const int r = i / rw, c = i - r * rw;
+        if (i < n) dst[r * kHS + c] = (uint16_t)sv[u];
       }
     }
-    if (more) put(u0 + ustep, cur ^ 1);
-    end(u0, chunk, sM);
+  };
+  // (d_item odd: 512 x d_item 2-byte elements need more than SIT slots per thread at 512 rows - the launcher then uses
+  // 256-row chunks, which fit for d_item <= 51; wider odd tables take the fp32-matrix path)
+  int chunk = pw, cur = 0;
+  __syncthreads();                       // (the zero fill above)
+  if (chunk < a.n_chunks) { fetch(chunk); put(chunk, 0); }
+  __syncthreads();
+  for (; chunk < a.n_chunks; chunk += a.wg_per_group) {
+    const int nxt = chunk + a.wg_per_group;
+    if (nxt < a.n_chunks) fetch(nxt);
+    const int64_t i0 = a.item_lo + (int64_t)chunk * a.crows;
+    const int ntile = a.crows >> 4;
+    // every row of the chunk is a rankable item (all chunks but the last one and, with exclude_pad, the one holding item 0):
+    // the epilogue then has no per-element validity arithmetic - at 12 MFMAs per item tile it would cost more issue slots
+    // than the MFMAs themselves
+    const bool full = a.item_hi - i0 >= a.crows && !(a.exclude_pad && i0 == 0);
+    for (int t = 0; t < ntile; ++t) {
+      const lds_u16* rowp = sE + (cur * kChunk16 + (t << 4) + li) * kHS + 8 * lq;
+      const bf16x8 a0 = *reinterpret_cast<const lds_bf16x8*>(rowp);
+      const bf16x8 a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + 32);
+      const int64_t item0 = i0 + (t << 4) + (lq << 2);
+#pragma unroll
+      for (int n = 0; n < NU; ++n) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tm = 2; tm >= 0; --tm) {               // smallest term first
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[n][tm][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr[n][tm][1], acc, 0, 0, 0);
+        }
+        if (srfrn) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += fs[n];
+        }
+        if (!full) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = item0 + e < a.item_hi && !(a.exclude_pad && item0 + e == 0);
+            acc[e] = ok ? acc[e] : -INFINITY;
+          }
+        }
+        elem(n, user0[n], item0, acc);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NU; ++n) end(n, user0[n], chunk);
+    if (nxt < a.n_chunks) put(nxt, cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
 }
 
-__global__ void __launch_bounds__(512, 2) topk_max16_kernel(const TopkArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  float m = -INFINITY;
-  topk_stream16(a,
-      [&](int) { m = -INFINITY; },
-      [&](int, int, int64_t, float v) { m = fmaxf(m, v); },
-      [&](int u0, int chunk, lds_f* sM) {
-        float mm = fmaxf(m, __shfl_xor(m, 16, 64));
+template <int NU>
+__global__ void __launch_bounds__(kWaves16 * 64) topk_max16_kernel(const TopkArgs a) {
+  const int lane = threadIdx.x & 63;
+  float m[NU];
+  topk_stream16<NU>(a,
+      [&](int n, int) { m[n] = -INFINITY; },
+      [&](int n, int, int64_t, const f32x4& v) { m[n] = fmaxf(fmaxf(m[n], fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); },
+      [&](int n, int u0, int chunk) {
+        float mm = fmaxf(m[n], __shfl_xor(m[n], 16, 64));
         mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
-        if (lane < 16) sM[wave * 16 + lane] = mm;
-        __syncthreads();
-        if (threadIdx.x < 16 && u0 + (int)threadIdx.x < a.B) {
-          float t = -INFINITY;
-          for (int w = 0; w < nw; ++w) t = fmaxf(t, sM[w * 16 + threadIdx.x]);
-          a.cmax[(int64_t)(u0 + threadIdx.x) * a.n_chunks + chunk] = t;
-        }
+        if (lane < 16 && u0 + lane < a.B) a.cmax[(int64_t)(u0 + lane) * a.n_chunks + chunk] = mm;
+        m[n] = -INFINITY;
       });
 }
 
-__global__ void __launch_bounds__(512, 2) topk_collect16_kernel(const TopkArgs a) {
+template <int NU>
+__global__ void __launch_bounds__(kWaves16 * 64) topk_collect16_kernel(const TopkArgs a) {
   const int li = threadIdx.x & 15;
-  float tau = INFINITY;
-  topk_stream16(a,
-      [&](int u0) { tau = u0 + li < a.B ? a.tau[u0 + li] : INFINITY; },
-      [&](int u0, int c, int64_t item, float v) {
-        if (v != -INFINITY && v >= tau) {
-          const int b = u0 + c;
+  float tau[NU];
+  topk_stream16<NU>(a,
+      [&](int n, int u0) { tau[n] = u0 + li < a.B ? a.tau[u0 + li] : INFINITY; },
+      [&](int n, int u0, int64_t item0, const f32x4& v) {
+        // hits are rare (about k per user over the whole catalog): one test of the four-item maximum, then a compact loop
+        if (!(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) >= tau[n])) return;
+        unsigned hm = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hm |= (v[e] != -INFINITY && v[e] >= tau[n]) ? 1u << e : 0u;
+        while (hm) {
+          const int e = __ffs(hm) - 1;
+          hm &= hm - 1;
+          const float ve = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
+          const int b = u0 + li;
           const int slot = atomicAdd(&a.ccnt[b], 1);
-          if (slot < kCandMax) a.cand[(int64_t)b * kCandMax + slot] = Cand{v, (int32_t)item};
+          if (slot < kCandMax) a.cand[(int64_t)b * kCandMax + slot] = Cand{ve, (int32_t)(item0 + e)};
           else a.ccnt[a.B] = 1;
         }
       },
-      [&](int, int, lds_f*) {});
+      [&](int, int, int) {});
 }
 
 __global__ void __launch_bounds__(512) topk_max_kernel(const TopkArgs a) {
@@ -472,12 +508,25 @@ __global__ void __launch_bounds__(512) topk_max_kernel(const TopkArgs a) {
       });
 }
 
-// tau[b] = k-th largest of cmax[b][:] (one wave per user; -inf if fewer than k finite maxima); also resets the cursor
+// tau[b] = k-th largest of cmax[b][:] (one wave per user; -inf if fewer than k finite maxima); also resets the cursor.
+// The row is staged in LDS once (all loads in flight together) and the k argmax rounds walk LDS: k rounds over global
+// memory were k x n_chunks / 64 dependent round trips (49 us at 1 M items).
 __global__ void __launch_bounds__(256) topk_tau_kernel(const TopkArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x * (blockDim.x >> 6) + wv;
   if (b >= a.B) return;
-  float* row = a.cmax + (int64_t)b * a.n_chunks;
+  const float* grow = a.cmax + (int64_t)b * a.n_chunks;
+  lds_f* row = (lds_f*)smem + (int64_t)wv * a.n_chunks;
+  for (int j0 = 0; j0 < a.n_chunks; j0 += 64 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = grow[min(j0 + u * 64 + lane, a.n_chunks - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + u * 64 + lane < a.n_chunks) row[j0 + u * 64 + lane] = v[u];
+  }
+  __builtin_amdgcn_wave_barrier();
   float tau = -INFINITY;
   for (int r = 0; r < a.k; ++r) {
     float bv = -INFINITY;
@@ -495,7 +544,6 @@ __global__ void __launch_bounds__(256) topk_tau_kernel(const TopkArgs a) {
     if (bp < 0) { tau = -INFINITY; break; }       // fewer than k chunks hold a finite score: keep everything finite
     tau = bv;
     if (lane == 0) row[bp] = -INFINITY;
-    __threadfence_block();
     __builtin_amdgcn_wave_barrier();
   }
   if (lane == 0) {
@@ -742,6 +790,29 @@ extern "C" int srfrd_predict_logits(const srfrd_layout* lay, const void* item_ta
   return (int)hipGetLastError();
 }
 
+// tau launch: the rows of 4 users per block while they fit the default 64 KiB of dynamic LDS, else one user per block
+// (with the > 64 KiB opt-in up to the CU's 160 KiB: 40 k chunks)
+static int launch_tau(const TopkArgs& a, hipStream_t st) {
+  const size_t row = (size_t)a.n_chunks * sizeof(float);
+  const int wpb = 4 * row <= 64 * 1024 ? 4 : 1;
+  const size_t lds = wpb * row;
+  if (lds > (size_t)kLdsLimit) return SRFRD_E_UNSUPPORTED;
+  if (lds > 64 * 1024) {
+    static std::mutex mu;
+    static size_t opted[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SRFRD_E_DEVICE;
+    std::lock_guard<std::mutex> lock(mu);
+    if (lds > opted[dev]) {
+      if (hipFuncSetAttribute((const void*)topk_tau_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SRFRD_E_DEVICE;
+      opted[dev] = lds;
+    }
+  }
+  hipLaunchKernelGGL(topk_tau_kernel, dim3((a.B + wpb - 1) / wpb), dim3(64 * wpb), lds, st, a);
+  return 0;
+}
+
 // workspace layout: [cmax B*nc f32][tau B f32][cursor B+1 i32 (+pad)][candidates B*kCandMax][fallback B*nc*k]
 static int64_t topk_off(int B, int k, int64_t nc, int which) {
   int64_t off = 0;
@@ -808,27 +879,49 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const void* item_table
   }
   a.user_splits = splits;
   hipStream_t st = (hipStream_t)stream;
-  if (lay->table_bf16 && lay->d_item <= 64 && getenv("SRFRD_TOPK_FP32") == nullptr) {
-    // bf16 table: the two threshold passes on the bf16 matrix cores (512-item chunks held in registers); the chunk maxima
-    // array is walked with the smaller chunk count, everything else (tau, candidate lists, selection, the armed exhaustive
-    // path with its own 256-item chunks) is shared
-    TopkArgs h = a;
-    h.n_chunks = (int)((item_hi - item_lo + kChunk16 - 1) / kChunk16);
-    int sp16 = 1;
-    double best16 = 1e30;
-    for (int sp = 1; sp <= user_tiles && sp <= 64; ++sp) {
-      const int64_t wgs = (int64_t)h.n_chunks * sp;
-      const double rounds = (double)((wgs + 511) / 512);
-      const double cost = rounds * (3.0 + (double)((user_tiles + sp - 1) / sp));
-      if (cost < best16) { best16 = cost; sp16 = sp; }
+  if (lay->table_bf16 && lay->d_item <= 64 && ((lay->d_item & 1) == 0 || lay->d_item <= 51) && getenv("SRFRD_TOPK_FP32") == nullptr) {
+    // bf16 table: the two threshold passes on the bf16 matrix cores (users in registers, item chunks streamed through LDS);
+    // the chunk-maxima array is walked with this path's chunk count, everything else (tau, candidate lists, selection, the
+    // armed exhaustive path with its own 256-item chunks) is shared
+    static std::mutex mu16;
+    static bool opted16[64] = {false};
+    {
+      std::lock_guard<std::mutex> lock(mu16);
+      if (!opted16[dev]) {
+        if (hipFuncSetAttribute((const void*)topk_max16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStream16Lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)topk_max16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStream16Lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)topk_collect16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStream16Lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)topk_collect16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStream16Lds) != hipSuccess)
+          return SRFRD_E_DEVICE;
+        opted16[dev] = true;
+      }
     }
-    h.user_splits = sp16;
-    hipLaunchKernelGGL(topk_max16_kernel, dim3(h.n_chunks * sp16), dim3(512), kStream16Lds, st, h);
-    hipLaunchKernelGGL(topk_tau_kernel, dim3((B + 3) / 4), dim3(256), 0, st, h);
-    hipLaunchKernelGGL(topk_collect16_kernel, dim3(h.n_chunks * sp16), dim3(512), kStream16Lds, st, h);
+    hipDeviceProp_t prop;
+    static int cu_cached[64] = {0};
+    if (cu_cached[dev] == 0) cu_cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    const int cu = cu_cached[dev];
+    const int64_t n_rows = item_hi - item_lo;
+    int nu = user_tiles > kWaves16 ? 2 : 1;
+    int groups = (user_tiles + kWaves16 * nu - 1) / (kWaves16 * nu);
+    int crows = kChunk16;
+    if ((lay->d_item & 1) != 0 || ((n_rows + crows - 1) / crows) * groups < 2 * (int64_t)cu) crows = 256;
+    int64_t nch = (n_rows + crows - 1) / crows;
+    if (nch * groups < cu && nu == 2) { nu = 1; groups = (user_tiles + kWaves16 - 1) / kWaves16; }
+    int per_group = cu / groups < 1 ? 1 : cu / groups;
+    if (per_group > nch) per_group = (int)nch;
+    TopkArgs h = a;
+    h.n_chunks = (int)nch;
+    h.crows = crows;
+    h.wg_per_group = per_group;
+    const dim3 grid16(groups * per_group), blk16(kWaves16 * 64);
+    if (nu == 2) hipLaunchKernelGGL(topk_max16_kernel<2>, grid16, blk16, kStream16Lds, st, h);
+    else hipLaunchKernelGGL(topk_max16_kernel<1>, grid16, blk16, kStream16Lds, st, h);
+    if (int trc = launch_tau(h, st)) return trc;
+    if (nu == 2) hipLaunchKernelGGL(topk_collect16_kernel<2>, grid16, blk16, kStream16Lds, st, h);
+    else hipLaunchKernelGGL(topk_collect16_kernel<1>, grid16, blk16, kStream16Lds, st, h);
   } else {
     hipLaunchKernelGGL(topk_max_kernel, dim3(n_chunks * splits), dim3(512), lds_stream, st, a);
-    hipLaunchKernelGGL(topk_tau_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a);
+    if (int trc = launch_tau(a, st)) return trc;
     hipLaunchKernelGGL(topk_collect_kernel, dim3(n_chunks * splits), dim3(512), lds_stream, st, a);
   }
   hipLaunchKernelGGL(topk_select_kernel, dim3((B + 3) / 4), dim3(256), 0, st, a, topk_idx, topk_val);

@@ -184,12 +184,16 @@ class _SRFRDBase(nn.Module):
         self._flat, self._slots = flat, slots
 
     # ---- bf16 item-table shadow (BASELINE configs[1] / [4] "bf16"; no reference counterpart: its table is fp32)
-    def use_bf16_table(self, on: bool = True):
+    def use_bf16_table(self, on: bool = True, auto_refresh: bool = True):
         """Gather item rows (embedding, pos / neg targets, predict / top-k candidates) from a bf16 shadow of the item
         table: half the gather bytes.  The parameter stays fp32 (state_dict, gradients, Adam unchanged); the shadow is
         rebuilt from it before every forward of the module path and rewritten by the fused optimizer in FusedTrainer.
-        Forward values then carry bf16-rounded embeddings (parity is held against the oracle with ``table_bf16``)."""
+        Forward values then carry bf16-rounded embeddings (parity is held against the oracle with ``table_bf16``).
+        ``auto_refresh=False`` (frozen weights, e.g. serving / an evaluation loop): the module path stops re-deriving the
+        shadow on every call (a pass over the whole table: 50 us at 1 M items); call ``refresh_bf16_table()`` yourself
+        after changing the item embeddings."""
         self._ensure_flat()
+        self._bf16_auto = bool(auto_refresh)
         if on:
             lay16 = _lib.Layout.from_buffer_copy(bytes(self.layout))
             lay16.table_bf16 = 1
@@ -221,7 +225,8 @@ class _SRFRDBase(nn.Module):
         """Refresh the MFMA-fragment-ordered copy of the encoder weights (srfrd_pack_weights) from the parameters (and the
         bf16 item-table shadow, when in use)."""
         lay, flat = self.layout, self._flat
-        self.refresh_bf16_table()
+        if getattr(self, "_bf16_auto", True):
+            self.refresh_bf16_table()
         if self._packed is None or self._packed.device != flat.device:
             self._packed = torch.empty(_lib.lib().srfrd_packed_floats(C.byref(lay)), device=flat.device, dtype=torch.float32)
         check(_lib.lib().srfrd_pack_weights(C.byref(lay), C.c_void_p(flat.data_ptr() + 4 * self.n_table_pad),
