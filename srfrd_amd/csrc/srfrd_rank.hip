@@ -414,31 +414,65 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
     // the epilogue then has no per-element validity arithmetic - at 12 MFMAs per item tile it would cost more issue slots
     // than the MFMAs themselves
     const bool full = a.item_hi - i0 >= a.crows && !(a.exclude_pad && i0 == 0);
-    for (int t = 0; t < ntile; ++t) {
-      const lds_u16* rowp = sE + (cur * kChunk16 + (t << 4) + li) * kHS + 8 * lq;
-      const bf16x8 a0 = *reinterpret_cast<const lds_bf16x8*>(rowp);
-      const bf16x8 a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + 32);
+    const lds_u16* rowp = sE + (cur * kChunk16 + li) * kHS + 8 * lq;
+    // the six-term accumulation chains of the NU user tiles, interleaved (independent chains back to back)
+    auto tile_mma = [&](const bf16x8& a0, const bf16x8& a1, f32x4 (&acc)[NU]) {
+#pragma unroll
+      for (int n = 0; n < NU; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tm = 2; tm >= 0; --tm) {                 // smallest term first
+#pragma unroll
+        for (int n = 0; n < NU; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[n][tm][0], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NU; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr[n][tm][1], acc[n], 0, 0, 0);
+      }
+    };
+    auto tile_out = [&](int t, f32x4 (&acc)[NU], bool masked) {
       const int64_t item0 = i0 + (t << 4) + (lq << 2);
 #pragma unroll
       for (int n = 0; n < NU; ++n) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tm = 2; tm >= 0; --tm) {               // smallest term first
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[n][tm][0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr[n][tm][1], acc, 0, 0, 0);
-        }
-        if (srfrn) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] += fs[n];
-        }
-        if (!full) {
+        for (int e = 0; e < 4; ++e) acc[n][e] += fs[n];          // (0 unless SRFRN: unconditional beats a per-element select)
+        if (masked) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const bool ok = item0 + e < a.item_hi && !(a.exclude_pad && item0 + e == 0);
-            acc[e] = ok ? acc[e] : -INFINITY;
+            acc[n][e] = ok ? acc[n][e] : -INFINITY;
           }
         }
-        elem(n, user0[n], item0, acc);
+        elem(n, user0[n], item0, acc[n]);
+      }
+    };
+    if (full) {
+      // software-pipelined over the item tiles: the MFMAs of tile t are in flight while tile t - 1 leaves its accumulators
+      // and the fragments of tile t + 1 arrive from LDS (two tiles per trip: the accumulator sets alternate statically)
+      f32x4 accA[NU], accB[NU];
+      bf16x8 a0 = *reinterpret_cast<const lds_bf16x8*>(rowp);
+      bf16x8 a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + 32);
+      tile_mma(a0, a1, accA);
+      for (int t = 1; t + 1 < ntile; t += 2) {
+        a0 = *reinterpret_cast<const lds_bf16x8*>(rowp + t * 16 * kHS);
+        a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + t * 16 * kHS + 32);
+        tile_mma(a0, a1, accB);
+        tile_out(t - 1, accA, false);
+        a0 = *reinterpret_cast<const lds_bf16x8*>(rowp + (t + 1) * 16 * kHS);
+        a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + (t + 1) * 16 * kHS + 32);
+        tile_mma(a0, a1, accA);
+        tile_out(t, accB, false);
+      }
+      // (ntile is even - 16 or 32: the loop leaves tile ntile - 2 in accA and tile ntile - 1 to do)
+      a0 = *reinterpret_cast<const lds_bf16x8*>(rowp + (ntile - 1) * 16 * kHS);
+      a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + (ntile - 1) * 16 * kHS + 32);
+      tile_mma(a0, a1, accB);
+      tile_out(ntile - 2, accA, false);
+      tile_out(ntile - 1, accB, false);
+    } else {
+      for (int t = 0; t < ntile; ++t) {
+        f32x4 acc[NU];
+        const bf16x8 a0 = *reinterpret_cast<const lds_bf16x8*>(rowp + t * 16 * kHS);
+        const bf16x8 a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + t * 16 * kHS + 32);
+        tile_mma(a0, a1, acc);
+        tile_out(t, acc, true);
       }
     }
 #pragma unroll
@@ -449,13 +483,20 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
   }
 }
 
+// max(a, b, c) as ONE v_max3_f32 (fmaxf compiles to a canonicalising v_max per operand first: the logits are never NaN)
+__device__ __forceinline__ float vmax3(float x, float y, float z) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
+
 template <int NU>
 __global__ void __launch_bounds__(kWaves16 * 64) topk_max16_kernel(const TopkArgs a) {
   const int lane = threadIdx.x & 63;
   float m[NU];
   topk_stream16<NU>(a,
       [&](int n, int) { m[n] = -INFINITY; },
-      [&](int n, int, int64_t, const f32x4& v) { m[n] = fmaxf(fmaxf(m[n], fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); },
+      [&](int n, int, int64_t, const f32x4& v) { m[n] = vmax3(vmax3(m[n], v[0], v[1]), v[2], v[3]); },
       [&](int n, int u0, int chunk) {
         float mm = fmaxf(m[n], __shfl_xor(m[n], 16, 64));
         mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
@@ -472,7 +513,7 @@ __global__ void __launch_bounds__(kWaves16 * 64) topk_collect16_kernel(const Top
       [&](int n, int u0) { tau[n] = u0 + li < a.B ? a.tau[u0 + li] : INFINITY; },
       [&](int n, int u0, int64_t item0, const f32x4& v) {
         // hits are rare (about k per user over the whole catalog): one test of the four-item maximum, then a compact loop
-        if (!(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) >= tau[n])) return;
+        if (!(vmax3(vmax3(v[0], v[1], v[2]), v[3], v[3]) >= tau[n])) return;
         unsigned hm = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) hm |= (v[e] != -INFINITY && v[e] >= tau[n]) ? 1u << e : 0u;
