@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const srfrd_layout ly
 using namespace srfrd;
 
 extern "C" int srfrd_long_launch_fwd(const void* args, int grid, int threads, void* stream);   // srfrd_encoder_fwd_long.hip
-extern "C" int srfrd_fwd_rows_launch(const void* args, int kind_variant, void* stream);        // srfrd_encoder_fwd_rows.hip
+extern "C" int srfrd_fwd_rows_launch(const void* args, int kind_variant, int mode, void* stream);   // srfrd_encoder_fwd_rows.hip
 
 extern "C" int64_t srfrd_aux_floats(const srfrd_layout* lay, int B, int L) {
   if (!lay || B <= 0 || L <= 0) return SRFRD_E_ARG;
@@ -120,16 +120,20 @@ static int encoder_fwd_impl(const srfrd_layout* lay, const void* item_table, con
   srfrd_debug_shape(lay, L, &a.dbg_slot, nullptr);
   const Geom g = make_geom(L, lay->D);
   const int64_t lds = fwd_lds_floats(g, lay->n_blocks) * 4;
-  if (lds > kLdsLimit && !pos_ids && !neg_ids && !save_x && !loss_part && !dbg && dropout_p == 0.0 && lay->D == 50 &&
-      getenv("SRFRD_NO_ROWS") == nullptr && getenv("SRFRD_GENERIC") == nullptr) {
-    // eval-mode hidden states of a long sequence: the row-owner kernel (K / V resident in LDS) where it covers the shape
+  const bool plain = !pos_ids && !neg_ids && !save_x && !loss_part && dropout_p == 0.0;       // eval-mode hidden states only
+  // the row-owner kernel (K / V resident in LDS): every long sequence it covers.  (Measured against the first-generation
+  // kernel where both fit: 185 vs 170 us per 512-sequence training forward at seq_len 100, 117 vs 59 us at seq_len 50 - with
+  // 7 or 4 row tiles it runs one or two waves per SIMD and their dependent chains are exposed; SRFRD_ROWS_ALWAYS selects it
+  // anyway, for tests.)
+  const bool rows_wanted = lds > kLdsLimit || getenv("SRFRD_ROWS_ALWAYS") != nullptr;
+  if (rows_wanted && !dbg && lay->D == 50 && getenv("SRFRD_NO_ROWS") == nullptr && getenv("SRFRD_GENERIC") == nullptr) {
     int kv = -1;
     if (lay->kind == SRFRD_SASREC) kv = 0;
     else if (lay->kind == SRFRD_SRFR && lay->d_item == 45) kv = 1;
     else if (lay->kind == SRFRD_SRFRN && lay->d_item == 45) kv = 2;
     else if (lay->kind >= SRFRD_SRFU_B && lay->d_item == 50) kv = 3;
     if (kv >= 0) {
-      rc = srfrd_fwd_rows_launch(&a, kv, stream);
+      rc = srfrd_fwd_rows_launch(&a, kv, plain ? 0 : 1, stream);
       if (rc != SRFRD_E_UNSUPPORTED) return rc;
     }
   }

@@ -92,3 +92,53 @@ def test_c4_geometry_fused_step_with_dropout_matches_oracle():
         hist.append(g_o)
         assert abs(float(loss.cpu()) - float(loss_o)) < TOL, step
     assert_post_adam(model.state_dict(), sd, hist, cfg.D)
+
+
+@pytest.mark.parametrize("kind,L", [("SRFRN", 128), ("SASRec", 200)])
+def test_long_fused_step_with_dropout_matches_oracle(kind, L):
+    """seq_len > 112 training: the row-owner forward in its training mode (dropout at the four sites, checkpoints written from
+    the transposed score layout, target logits, loss sums) feeding the global-scratch backward - two fused Adam steps with
+    dropout 0.5 against the oracle's steps with the same masks."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, random_sd
+    from tests.helpers import assert_post_adam, oracle_step_with_grads
+    I, B, base = 300, 5, 77
+    cfg = O.Cfg(kind, I, L, 50, dropout=0.5) if kind == "SASRec" else O.Cfg(kind, I, L, 45, d_fake=5, dropout=0.5)
+    sd = random_sd(cfg, 3)
+    model = build_model(cfg, {k: v.clone() for k, v in sd.items()}).train()
+    tr = srfrd_amd.FusedTrainer(model, batch_size=B, seq_len=L, lr=1e-3, betas=(0.9, 0.98), seed=base, use_graph=False)
+    opt = O.Adam(sd)
+    hist = []
+    for step in range(2):
+        batch = srfrd_amd.synthetic_batch(I, L, B, seed=60 + step, device="cpu")
+        loss = tr.step(*cuda(*batch))
+        loss_o, g_o = oracle_step_with_grads(cfg, sd, opt, batch[1:], train=True, seed=O.step_seed(base, step + 1), b0=0)
+        hist.append(g_o)
+        assert abs(float(loss.cpu()) - float(loss_o)) < TOL, step
+    assert_post_adam(model.state_dict(), sd, hist, cfg.D)
+
+
+def test_row_owner_forward_at_the_default_geometry(monkeypatch):
+    """The row-owner kernel forced onto seq_len 50 (one row tile per wave): eval forward with target logits and a fused
+    training step with dropout, against the oracle - the same arithmetic contract as the first-generation kernel."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, maxerr, random_sd
+    from tests.helpers import assert_post_adam, oracle_step_with_grads
+    monkeypatch.setenv("SRFRD_ROWS_ALWAYS", "1")
+    I, L, B, base = 300, 50, 6, 5
+    cfg = O.Cfg("SRFRN", I, L, 45, d_fake=5, dropout=0.5)
+    sd = random_sd(cfg, 8)
+    model = build_model(cfg, {k: v.clone() for k, v in sd.items()})
+    batch = srfrd_amd.synthetic_batch(I, L, B, seed=9, device="cpu")
+    model.eval()
+    with torch.no_grad():
+        h, pl, nl = model(None, *cuda(*batch[1:]))
+    ho, plo, nlo = O.forward(cfg, sd, *batch[1:])
+    assert maxerr(h, ho) < TOL and maxerr(pl, plo) < TOL and maxerr(nl, nlo) < TOL
+    model.train()
+    tr = srfrd_amd.FusedTrainer(model, batch_size=B, seq_len=L, lr=1e-3, betas=(0.9, 0.98), seed=base, use_graph=False)
+    opt = O.Adam(sd)
+    loss = tr.step(*cuda(*batch))
+    loss_o, g_o = oracle_step_with_grads(cfg, sd, opt, batch[1:], train=True, seed=O.step_seed(base, 1), b0=0)
+    assert abs(float(loss.cpu()) - float(loss_o)) < TOL
+    assert_post_adam(model.state_dict(), sd, [g_o], cfg.D)
