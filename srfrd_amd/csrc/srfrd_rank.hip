@@ -304,18 +304,26 @@ constexpr int kHS = 72;                         // bf16 row stride of an item ro
 constexpr int kStream16Lds = 2 * kChunk16 * kHS * 2;
 
 // begin(ut, user0) once per owned user tile; elem(ut, user0, item0, v) with the lane's four consecutive items of user user0 + li;
-// end(ut, user0, chunk) once per (user tile, chunk)
-template <int NU, class BEG, class ELEM, class END>
+// end(ut, user0, chunk) once per (user tile, chunk).
+// SPLIT_E = false: bf16 table (rows copied as they are; 512 / 256-row chunks, two LDS buffers, one barrier per chunk).
+// SPLIT_E = true : fp32 table.  A chunk's rows are split into three exact bf16 planes e1 + e2 + e3 while they are staged
+//   (256-row chunks, ONE buffer of three planes = 110 KB: the next chunk waits in registers and is split / written between
+//   two barriers), and a logit takes the six products whose weight is above 2^-24 of the largest one - h1e1, h1e2, h2e1,
+//   h1e3, h2e2, h3e1 (smallest first) - twelve bf16 MFMAs per 16 x 16 tile against thirteen fp32 ones at twice the
+//   cycles each, with fp32-grade results (the dropped products are at the level of an fp32 rounding).
+template <int NU, bool SPLIT_E, class BEG, class ELEM, class END>
 __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, ELEM&& elem, END&& end) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NE = SPLIT_E ? 3 : 1;                  // bf16 planes of an item chunk
+  constexpr int CH = SPLIT_E ? 256 : kChunk16;         // rows of a plane
   const int tid = threadIdx.x, nthr = kWaves16 * 64;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lq = lane >> 4;
   const srfrd_layout& ly = a.ly;
   const int di = ly.d_item, dout = ly.d_out, D = ly.D;
   const bool srfrn = ly.kind == SRFRD_SRFRN;
-  lds_u16* sE = (lds_u16*)smem;                               // [2][kChunk16][kHS]
+  lds_u16* sE = (lds_u16*)smem;                               // [2][512][kHS]  or  [3][256][kHS]
   const int group = blockIdx.x / a.wg_per_group, pw = blockIdx.x - group * a.wg_per_group;
-  for (int idx = tid; idx < 2 * kChunk16 * kHS / 2; idx += nthr) ((lds_u32*)sE)[idx] = 0;      // k-padding columns stay zero
+  for (int idx = tid; idx < kStream16Lds / 4; idx += nthr) ((lds_u32*)sE)[idx] = 0;      // k-padding columns stay zero
   // ---- this wave's users: split hidden fragments (lane (li, lq): user tile row li, k = 32 ks + 8 lq + 0..7) and side terms
   bf16x8 bfr[NU][3][2];
   float fs[NU];
@@ -351,11 +359,10 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
     fs[n] = sacc;
     begin(n, user0[n]);
   }
-  // ---- item chunks: table -> registers -> LDS; thread t owns dwords t, t + nthr, ... of the chunk's [crows][d_item / 2]
-  const uint16_t* tab = (const uint16_t*)a.table;
-  const bool dw = (di & 1) == 0;                       // rows are whole dwords (d_item even): 4-byte copies
-  const int rw = dw ? di >> 1 : di;                    // copy elements per row
-  constexpr int SIT = 13;                              // 512 rows x 25 dwords over 1024 threads
+  // ---- item chunks: table -> registers -> LDS; thread t owns copy elements t, t + nthr, ... of the chunk
+  const bool dw = !SPLIT_E && (di & 1) == 0;           // bf16 rows that are whole dwords (d_item even): 4-byte copies
+  const int rw = SPLIT_E ? di : (dw ? di >> 1 : di);   // copy elements per row
+  constexpr int SIT = 13;                              // 512 x 25 dwords / 256 x 50 floats over 1024 threads
   uint32_t sv[SIT];
   // (the thread index is laundered at every use: its per-slot row / column split is cheap to redo and would otherwise
   // sit in 26 registers for the whole launch)
@@ -365,12 +372,16 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
     const int n = nrow * rw;
     int tl = tid;
     asm volatile("" : "+v"(tl));
-    if (dw) {
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(tab + i0 * di);
+    if (SPLIT_E) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>((const float*)a.table + i0 * di);
+#pragma unroll
+      for (int u = 0; u < SIT; ++u) sv[u] = src[min(u * nthr + tl, n - 1)];
+    } else if (dw) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>((const uint16_t*)a.table + i0 * di);
 #pragma unroll
       for (int u = 0; u < SIT; ++u) sv[u] = src[min(u * nthr + tl, n - 1)];
     } else {
-      const uint16_t* src = tab + i0 * di;
+      const uint16_t* src = (const uint16_t*)a.table + i0 * di;
 #pragma unroll
       for (int u = 0; u < SIT; ++u) sv[u] = (uint32_t)src[min(u * nthr + tl, n - 1)];
     }
@@ -381,8 +392,24 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
     const int n = nrow * rw;
     int tl = tid;
     asm volatile("" : "+v"(tl));
-    if (dw) {
-      lds_u32* dst = (lds_u32*)sE + buf * kChunk16 * (kHS / 2);
+    if (SPLIT_E) {
+#pragma unroll
+      for (int u = 0; u < SIT; ++u) {
+        const int i = u * nthr + tl;
+        const int r = i / rw, c = i - r * rw;
+        if (i < n) {
+          const float x = __uint_as_float(sv[u]);
+          const uint16_t e1 = f32_to_bf16(x);
+          const float r1 = x - bf16_to_f32(e1);
+          const uint16_t e2 = f32_to_bf16(r1);
+          const float r2 = r1 - bf16_to_f32(e2);
+          sE[(0 * CH + r) * kHS + c] = e1;
+          sE[(1 * CH + r) * kHS + c] = e2;
+          sE[(2 * CH + r) * kHS + c] = f32_to_bf16(r2);
+        }
+      }
+    } else if (dw) {
+      lds_u32* dst = (lds_u32*)sE + buf * CH * (kHS / 2);
 #pragma unroll
       for (int u = 0; u < SIT; ++u) {
         const int i = u * nthr + tl;
@@ -390,7 +417,7 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
         if (i < n) dst[r * (kHS / 2) + c] = sv[u];
       }
     } else {
-      lds_u16* dst = sE + buf * kChunk16 * kHS;
+      lds_u16* dst = sE + buf * CH * kHS;
 #pragma unroll
       for (int u = 0; u < SIT; ++u) {
         const int i = u * nthr + tl;
@@ -399,8 +426,9 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
       }
     }
   };
-  // (d_item odd: 512 x d_item 2-byte elements need more than SIT slots per thread at 512 rows - the launcher then uses
-  // 256-row chunks, which fit for d_item <= 51; wider odd tables take the fp32-matrix path)
+  // (d_item odd, bf16: 512 x d_item 2-byte elements need more than SIT slots per thread at 512 rows - the launcher then uses
+  // 256-row chunks, which fit for d_item <= 51; fp32: 256 x d_item <= 13 x 1024 for d_item <= 52; wider tables take the
+  // fp32-matrix path)
   int chunk = pw, cur = 0;
   __syncthreads();                       // (the zero fill above)
   if (chunk < a.n_chunks) { fetch(chunk); put(chunk, 0); }
@@ -414,17 +442,38 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
     // the epilogue then has no per-element validity arithmetic - at 12 MFMAs per item tile it would cost more issue slots
     // than the MFMAs themselves
     const bool full = a.item_hi - i0 >= a.crows && !(a.exclude_pad && i0 == 0);
-    const lds_u16* rowp = sE + (cur * kChunk16 + li) * kHS + 8 * lq;
-    // the six-term accumulation chains of the NU user tiles, interleaved (independent chains back to back)
-    auto tile_mma = [&](const bf16x8& a0, const bf16x8& a1, f32x4 (&acc)[NU]) {
+    const lds_u16* rowp = sE + ((SPLIT_E ? 0 : cur) * CH + li) * kHS + 8 * lq;
+    struct AF { bf16x8 f[NE][2]; };
+    auto tile_load = [&](int t) {
+      AF r;
+#pragma unroll
+      for (int pl = 0; pl < NE; ++pl) {
+        r.f[pl][0] = *reinterpret_cast<const lds_bf16x8*>(rowp + (pl * CH + t * 16) * kHS);
+        r.f[pl][1] = *reinterpret_cast<const lds_bf16x8*>(rowp + (pl * CH + t * 16) * kHS + 32);
+      }
+      return r;
+    };
+    // the accumulation chains of the NU user tiles, interleaved (independent chains back to back), smallest products first
+    auto tile_mma = [&](const AF& af, f32x4 (&acc)[NU]) {
 #pragma unroll
       for (int n = 0; n < NU; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (SPLIT_E) {
+        constexpr int TH[6] = {2, 1, 0, 1, 0, 0}, TE[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-      for (int tm = 2; tm >= 0; --tm) {                 // smallest term first
+        for (int q = 0; q < 6; ++q) {
 #pragma unroll
-        for (int n = 0; n < NU; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[n][tm][0], acc[n], 0, 0, 0);
+          for (int n = 0; n < NU; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.f[TE[q]][0], bfr[n][TH[q]][0], acc[n], 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < NU; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr[n][tm][1], acc[n], 0, 0, 0);
+          for (int n = 0; n < NU; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.f[TE[q]][1], bfr[n][TH[q]][1], acc[n], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int tm = 2; tm >= 0; --tm) {
+#pragma unroll
+          for (int n = 0; n < NU; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.f[0][0], bfr[n][tm][0], acc[n], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < NU; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.f[0][1], bfr[n][tm][1], acc[n], 0, 0, 0);
+        }
       }
     };
     auto tile_out = [&](int t, f32x4 (&acc)[NU], bool masked) {
@@ -447,39 +496,35 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
       // software-pipelined over the item tiles: the MFMAs of tile t are in flight while tile t - 1 leaves its accumulators
       // and the fragments of tile t + 1 arrive from LDS (two tiles per trip: the accumulator sets alternate statically)
       f32x4 accA[NU], accB[NU];
-      bf16x8 a0 = *reinterpret_cast<const lds_bf16x8*>(rowp);
-      bf16x8 a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + 32);
-      tile_mma(a0, a1, accA);
+      tile_mma(tile_load(0), accA);
       for (int t = 1; t + 1 < ntile; t += 2) {
-        a0 = *reinterpret_cast<const lds_bf16x8*>(rowp + t * 16 * kHS);
-        a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + t * 16 * kHS + 32);
-        tile_mma(a0, a1, accB);
+        tile_mma(tile_load(t), accB);
         tile_out(t - 1, accA, false);
-        a0 = *reinterpret_cast<const lds_bf16x8*>(rowp + (t + 1) * 16 * kHS);
-        a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + (t + 1) * 16 * kHS + 32);
-        tile_mma(a0, a1, accA);
+        tile_mma(tile_load(t + 1), accA);
         tile_out(t, accB, false);
       }
       // (ntile is even - 16 or 32: the loop leaves tile ntile - 2 in accA and tile ntile - 1 to do)
-      a0 = *reinterpret_cast<const lds_bf16x8*>(rowp + (ntile - 1) * 16 * kHS);
-      a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + (ntile - 1) * 16 * kHS + 32);
-      tile_mma(a0, a1, accB);
+      tile_mma(tile_load(ntile - 1), accB);
       tile_out(ntile - 2, accA, false);
       tile_out(ntile - 1, accB, false);
     } else {
       for (int t = 0; t < ntile; ++t) {
         f32x4 acc[NU];
-        const bf16x8 a0 = *reinterpret_cast<const lds_bf16x8*>(rowp + t * 16 * kHS);
-        const bf16x8 a1 = *reinterpret_cast<const lds_bf16x8*>(rowp + t * 16 * kHS + 32);
-        tile_mma(a0, a1, acc);
+        tile_mma(tile_load(t), acc);
         tile_out(t, acc, true);
       }
     }
 #pragma unroll
     for (int n = 0; n < NU; ++n) end(n, user0[n], chunk);
-    if (nxt < a.n_chunks) put(nxt, cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    if (SPLIT_E) {
+      __syncthreads();                   // every wave is done reading the (single) buffer
+      if (nxt < a.n_chunks) put(nxt, 0);
+      __syncthreads();
+    } else {
+      if (nxt < a.n_chunks) put(nxt, cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 }
 
@@ -490,11 +535,11 @@ __device__ __forceinline__ float vmax3(float x, float y, float z) {
   return r;
 }
 
-template <int NU>
+template <int NU, bool SPLIT_E>
 __global__ void __launch_bounds__(kWaves16 * 64) topk_max16_kernel(const TopkArgs a) {
   const int lane = threadIdx.x & 63;
   float m[NU];
-  topk_stream16<NU>(a,
+  topk_stream16<NU, SPLIT_E>(a,
       [&](int n, int) { m[n] = -INFINITY; },
       [&](int n, int, int64_t, const f32x4& v) { m[n] = vmax3(vmax3(m[n], v[0], v[1]), v[2], v[3]); },
       [&](int n, int u0, int chunk) {
@@ -505,11 +550,11 @@ __global__ void __launch_bounds__(kWaves16 * 64) topk_max16_kernel(const TopkArg
       });
 }
 
-template <int NU>
+template <int NU, bool SPLIT_E>
 __global__ void __launch_bounds__(kWaves16 * 64) topk_collect16_kernel(const TopkArgs a) {
   const int li = threadIdx.x & 15;
   float tau[NU];
-  topk_stream16<NU>(a,
+  topk_stream16<NU, SPLIT_E>(a,
       [&](int n, int u0) { tau[n] = u0 + li < a.B ? a.tau[u0 + li] : INFINITY; },
       [&](int n, int u0, int64_t item0, const f32x4& v) {
         // hits are rare (about k per user over the whole catalog): one test of the four-item maximum, then a compact loop
@@ -920,20 +965,25 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const void* item_table
   }
   a.user_splits = splits;
   hipStream_t st = (hipStream_t)stream;
-  if (lay->table_bf16 && lay->d_item <= 64 && ((lay->d_item & 1) == 0 || lay->d_item <= 51) && getenv("SRFRD_TOPK_FP32") == nullptr) {
-    // bf16 table: the two threshold passes on the bf16 matrix cores (users in registers, item chunks streamed through LDS);
-    // the chunk-maxima array is walked with this path's chunk count, everything else (tau, candidate lists, selection, the
-    // armed exhaustive path with its own 256-item chunks) is shared
+  const bool bf16_tab = lay->table_bf16 != 0;
+  const bool stream16 = getenv("SRFRD_TOPK_FP32") == nullptr &&
+                        (bf16_tab ? (lay->d_item <= 64 && ((lay->d_item & 1) == 0 || lay->d_item <= 51)) : lay->d_item <= 52);
+  if (stream16) {
+    // the two threshold passes on the bf16 matrix cores (users in registers, item chunks streamed through LDS): a bf16
+    // table as it is, an fp32 table split into three exact bf16 planes while it is staged.  The chunk-maxima array is walked
+    // with this path's chunk count, everything else (tau, candidate lists, selection, the armed exhaustive path with its own
+    // 256-item chunks) is shared
     static std::mutex mu16;
     static bool opted16[64] = {false};
     {
       std::lock_guard<std::mutex> lock(mu16);
       if (!opted16[dev]) {
-        if (hipFuncSetAttribute((const void*)topk_max16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStream16Lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)topk_max16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStream16Lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)topk_collect16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kStream16Lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)topk_collect16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kStream16Lds) != hipSuccess)
-          return SRFRD_E_DEVICE;
+        const void* fns[8] = {(const void*)topk_max16_kernel<1, false>, (const void*)topk_max16_kernel<2, false>,
+                              (const void*)topk_collect16_kernel<1, false>, (const void*)topk_collect16_kernel<2, false>,
+                              (const void*)topk_max16_kernel<1, true>, (const void*)topk_max16_kernel<2, true>,
+                              (const void*)topk_collect16_kernel<1, true>, (const void*)topk_collect16_kernel<2, true>};
+        for (const void* fn : fns)
+          if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kStream16Lds) != hipSuccess) return SRFRD_E_DEVICE;
         opted16[dev] = true;
       }
     }
@@ -944,7 +994,7 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const void* item_table
     const int64_t n_rows = item_hi - item_lo;
     int nu = user_tiles > kWaves16 ? 2 : 1;
     int groups = (user_tiles + kWaves16 * nu - 1) / (kWaves16 * nu);
-    int crows = kChunk16;
+    int crows = bf16_tab ? kChunk16 : 256;
     if ((lay->d_item & 1) != 0 || ((n_rows + crows - 1) / crows) * groups < 2 * (int64_t)cu) crows = 256;
     int64_t nch = (n_rows + crows - 1) / crows;
     if (nch * groups < cu && nu == 2) { nu = 1; groups = (user_tiles + kWaves16 - 1) / kWaves16; }
@@ -955,11 +1005,15 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const void* item_table
     h.crows = crows;
     h.wg_per_group = per_group;
     const dim3 grid16(groups * per_group), blk16(kWaves16 * 64);
-    if (nu == 2) hipLaunchKernelGGL(topk_max16_kernel<2>, grid16, blk16, kStream16Lds, st, h);
-    else hipLaunchKernelGGL(topk_max16_kernel<1>, grid16, blk16, kStream16Lds, st, h);
+#define SRFRD_L16(KERNEL) do { \
+      if (bf16_tab) { if (nu == 2) hipLaunchKernelGGL((KERNEL<2, false>), grid16, blk16, kStream16Lds, st, h); \
+                      else hipLaunchKernelGGL((KERNEL<1, false>), grid16, blk16, kStream16Lds, st, h); } \
+      else { if (nu == 2) hipLaunchKernelGGL((KERNEL<2, true>), grid16, blk16, kStream16Lds, st, h); \
+             else hipLaunchKernelGGL((KERNEL<1, true>), grid16, blk16, kStream16Lds, st, h); } } while (0)
+    SRFRD_L16(topk_max16_kernel);
     if (int trc = launch_tau(h, st)) return trc;
-    if (nu == 2) hipLaunchKernelGGL(topk_collect16_kernel<2>, grid16, blk16, kStream16Lds, st, h);
-    else hipLaunchKernelGGL(topk_collect16_kernel<1>, grid16, blk16, kStream16Lds, st, h);
+    SRFRD_L16(topk_collect16_kernel);
+#undef SRFRD_L16
   } else {
     hipLaunchKernelGGL(topk_max_kernel, dim3(n_chunks * splits), dim3(512), lds_stream, st, a);
     if (int trc = launch_tau(a, st)) return trc;
