@@ -14,6 +14,7 @@ using namespace srfrd;
 
 extern "C" int srfrd_long_launch_bwd(const void* args, int grid, int threads, int variant, void* stream);   // srfrd_encoder_bwd_long.hip
 extern "C" int srfrd_bwd_slots_launch(const void* args, int grid, int L, int kind_variant, void* stream);    // srfrd_encoder_bwd_slots.hip
+extern "C" int srfrd_bwd_chunks_launch(const void* args, int grid, int kind_variant, void* stream);          // srfrd_encoder_bwd_chunks.hip
 
 extern "C" int srfrd_bwd_grid(int B) {
   if (B <= 0) return SRFRD_E_ARG;
@@ -60,6 +61,15 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table
     if (kv >= 0) {
       rc = srfrd_bwd_slots_launch(&a, grid, L, kv, stream);
       if (rc != SRFRD_E_UNSUPPORTED) return rc;
+      if (getenv("SRFRD_NO_CHUNKS") == nullptr && scratch) {     // other lengths up to 208: the row-chunked kernel
+        const int64_t stride = (bwd_lds_floats(g, lay->n_blocks) + 2 * kSlack + 63) & ~63ll;
+        if (scratch_floats >= stride * grid) {
+          a.scratch = scratch;
+          a.scratch_stride = stride;
+          rc = srfrd_bwd_chunks_launch(&a, grid, kv, stream);
+          if (rc != SRFRD_E_UNSUPPORTED) return rc;
+        }
+      }
     }
   }
   if (lds > kLdsLimit) {                       // long sequence: working set in the caller's global scratch
