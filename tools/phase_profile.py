@@ -23,7 +23,7 @@ def build():
     os.makedirs(tmp + "/include", exist_ok=True)
     for f in os.listdir(CSRC):
         open(f"{tmp}/srfrd_amd/csrc/{f}", "w").write(open(os.path.join(CSRC, f)).read())
-    for which in ("fwd", "bwd", "bwd_slots"):
+    for which in ("fwd", "bwd", "bwd_slots", "bwd_chunks"):
         fname = f"srfrd_encoder_{which}_kernel.inc"
         out = _stamp_file(os.path.join(CSRC, fname), which, labels)
         open(f"{tmp}/srfrd_amd/csrc/{fname}", "w").write("\n".join(out))
@@ -115,8 +115,9 @@ def run():
                 print(f"  {i:3d} {float(mean[i]):9.0f} {100 * float(mean[i]) / tot:5.1f}%  {labels.get(f'{which}:{i}', '')}")
 
 
-def run_c4():
-    """seq_len 100 fused training step (BASELINE configs[3] geometry): the slot-placed backward, phase by phase"""
+def run_c4(I=200_000, L=100, which="bwd_slots"):
+    """seq_len 100 fused training step (BASELINE configs[3] geometry): the slot-placed backward, phase by phase
+    (--c5: seq_len 200, the row-chunked backward)"""
     import ctypes as C
     import json
     import torch
@@ -125,7 +126,7 @@ def run_c4():
     from srfrd_amd import _lib
     from srfrd_amd._lib import check, ptr
     labels = json.load(open(OUT + ".labels.json"))
-    I, L, B, D = 200_000, 100, 512, 50
+    B, D = 512, 50
     torch.manual_seed(0)
     m = srfrd_amd.SASRec(I, L, D, 0.5, 2, 1, "cuda")
     for _, p in m.named_parameters():
@@ -160,10 +161,10 @@ def run_c4():
     used = d[d.sum(1) > 0]
     mean = used.mean(0)
     tot = float(mean.sum())
-    print(f"== bwd_slots: {used.shape[0]} workgroups, {tot:.0f} ticks (100 MHz -> {tot / 100:.1f} us) per workgroup")
+    print(f"== {which}: {used.shape[0]} workgroups, {tot:.0f} ticks per workgroup")
     for i in range(128):
         if mean[i] > 0:
-            print(f"  {i:3d} {float(mean[i]):9.0f} {100 * float(mean[i]) / tot:5.1f}%  {labels.get(f'bwd_slots:{i}', '')}")
+            print(f"  {i:3d} {float(mean[i]):9.0f} {100 * float(mean[i]) / tot:5.1f}%  {labels.get(f'{which}:{i}', '')}")
 
 
 if __name__ == "__main__":
@@ -173,3 +174,5 @@ if __name__ == "__main__":
         run()
     if "--c4" in sys.argv:
         run_c4()
+    if "--c5" in sys.argv:
+        run_c4(1_000_000, 200, "bwd_chunks")
