@@ -374,9 +374,11 @@ struct WFrag {
   float4 q[kPackKC];
   float bias;
 };
-__device__ __forceinline__ WFrag load_wfrag(PackedB b, const float* bias, int nbias, int n_tiles) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// (tid_: the caller's - possibly laundered - copy of threadIdx.x: a load whose address derives from an opaque value cannot be
+// hoisted out of the caller's loop, where it would pin 53 registers for the loop's whole life)
+__device__ __forceinline__ WFrag load_wfrag(PackedB b, const float* bias, int nbias, int n_tiles, int tid_) {
+  const int lane = tid_ & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int nt = wave % n_tiles;
   WFrag f;
 #pragma unroll
@@ -384,6 +386,9 @@ __device__ __forceinline__ WFrag load_wfrag(PackedB b, const float* bias, int nb
   const int c = (nt << 4) + (lane & 15);
   f.bias = (bias != nullptr && c < nbias) ? bias[c] : 0.f;
   return f;
+}
+__device__ __forceinline__ WFrag load_wfrag(PackedB b, const float* bias, int nbias, int n_tiles) {
+  return load_wfrag(b, bias, nbias, n_tiles, (int)threadIdx.x);
 }
 
 // packed-weight GEMM: C = A * Bpacked (+ bias[col]); k_end <= 64, a multiple of 4.  Exactly k_end / 4 MFMA k-steps are
