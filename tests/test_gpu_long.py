@@ -14,7 +14,7 @@ def _setup(kind, L, B=6, I=300, seed=0):
     from tests.gpu_util import build_model, random_sd
     if kind == "SASRec":
         cfg = O.Cfg(kind, I, L, 50)
-    elif kind == "SRFRN":
+    elif kind in ("SRFRN", "SRFR"):
         cfg = O.Cfg(kind, I, L, 45, d_fake=5)
     else:
         cfg = O.Cfg(kind, I, L, 50, n_labels=3)
@@ -38,9 +38,11 @@ def test_long_forward_matches_oracle(kind, L):
     assert maxerr(h, ho) < TOL and maxerr(pl, plo) < TOL and maxerr(nl, nlo) < TOL
 
 
-@pytest.mark.parametrize("kind,L", [("SASRec", 100), ("SRFRN", 100), ("SASRec", 200)])
+@pytest.mark.parametrize("kind,L", [("SASRec", 100), ("SRFRN", 100), ("SASRec", 200), ("SRFR", 128), ("SRFU_B", 144)])
 def test_c4_c5_length_training_matches_oracle(kind, L):
-    """seq_len 100 / 200 (BASELINE configs[3] / [4] geometry): gradients, loss and two fused Adam steps vs the oracle."""
+    """seq_len 100 / 200 (BASELINE configs[3] / [4] geometry) and two lengths in between for the other kinds: gradients, loss
+    and two fused Adam steps vs the oracle.  The fused step runs the slot-placed backward at 100 and the row-chunked one
+    above it (three chunks exactly at 144, a 32-row tail at 128, an 8-row tail at 200)."""
     import srfrd_amd
     from srfrd_amd import _lib
     from tests.gpu_util import cuda, maxerr
