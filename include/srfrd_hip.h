@@ -83,14 +83,14 @@ typedef struct srfrd_layout {
 int srfrd_layout_init(srfrd_layout* lay, int kind, int n_items, int max_len, int d_item, int d_fake,
                       int n_labels, int n_blocks, int n_heads);
 
-/* [host] capability query: dynamic LDS bytes the fused forward / backward kernels need for sequence length L
- * (0 if L does not fit the 160 KiB LDS of a gfx950 CU: such shapes take the global-scratch build, see
- * srfrd_scratch_floats). */
+/* [host] capability query: dynamic LDS bytes the first-generation fused forward / backward kernels need for sequence
+ * length L (0 if that working set does not fit the 160 KiB LDS of a gfx950 CU: such shapes run the long-sequence kernels -
+ * LDS-resident for hidden width 50 up to L = 208, a global-scratch build beyond - and need srfrd_scratch_floats). */
 int srfrd_lds_bytes(const srfrd_layout* lay, int L, int64_t* fwd_bytes, int64_t* bwd_bytes);
 
-/* [host] floats of global scratch the forward / backward need for (B, L): 0 when the sequence's working set fits LDS;
- * otherwise the kernels run their long-sequence build, which keeps that working set in `scratch` (one slice per
- * workgroup) - every shape runs on the GPU, the LDS-resident shapes run faster. */
+/* [host] floats of global scratch the forward / backward need for (B, L): 0 when the first-generation working set fits
+ * LDS; otherwise one slice per workgroup: the long-sequence kernels keep what crosses their passes there (the row-chunked
+ * backward: three [L][D] intermediates), the global-scratch build its whole working set - every shape runs on the GPU. */
 int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64_t* fwd_floats, int64_t* bwd_floats);
 
 /* [host] floats of the forward's `save_aux` checkpoint buffer for (B, L): per block and sequence the FFN hidden
