@@ -59,7 +59,7 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table
     else if (lay->kind == SRFRD_SRFRN && lay->d_item == 45) kv = 2;
     else if (lay->kind >= SRFRD_SRFU_B && lay->d_item == 50) kv = 3;
     if (kv >= 0) {
-      rc = srfrd_bwd_slots_launch(&a, grid, L, kv, stream);
+      rc = getenv("SRFRD_NO_SLOT_KERNEL") ? SRFRD_E_UNSUPPORTED : srfrd_bwd_slots_launch(&a, grid, L, kv, stream);
       if (rc != SRFRD_E_UNSUPPORTED) return rc;
       if (getenv("SRFRD_NO_CHUNKS") == nullptr && scratch) {     // other lengths up to 208: the row-chunked kernel
         const int64_t stride = (bwd_lds_floats(g, lay->n_blocks) + 2 * kSlack + 63) & ~63ll;
