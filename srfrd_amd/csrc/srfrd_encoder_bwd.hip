@@ -50,9 +50,10 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table
 #else
   const bool taps = dbg != nullptr;
 #endif
-  if (lds > kLdsLimit && pos_ids && neg_ids && fused_bce && !d_hidden && !taps && lay->D == 50 &&
+  if (lds > kLdsLimit && !taps && lay->D == 50 &&
       getenv("SRFRD_NO_SLOTS") == nullptr && getenv("SRFRD_GENERIC") == nullptr) {
-    // fused training step of a long sequence: the slot-placed, query-chunked LDS-resident kernel where one is built
+    // a long sequence (fused training step or autograd backward): the slot-placed, query-chunked LDS-resident kernel where
+    // one is built, the row-chunked one otherwise
     int kv = -1;
     if (lay->kind == SRFRD_SASREC) kv = 0;
     else if (lay->kind == SRFRD_SRFR && lay->d_item == 45) kv = 1;
