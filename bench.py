@@ -328,8 +328,16 @@ def explore(args, cfg, model, dev, rank):
             loss.backward()
             opt.step()
     else:
-        tr = srfrd_amd.FusedTrainer(model, B, L, use_graph=not args.no_graph)
-        fn = lambda: tr.step(u, seq, rsq, pos, prs, neg, nrs)
+        # as on the contract line: the batch is resident in the trainer's input ring, the step consumes it in place
+        tr = srfrd_amd.FusedTrainer(model, B, L, use_graph=not args.no_graph, slots=2, deterministic=args.deterministic)
+        packed = srfrd_amd.synthetic_batch(cfg["n_items"], L, B, seed=1, rank=rank, device=dev, packed=True)[1]
+        for k in range(2):
+            tr.ids_ring[k].copy_(packed)
+        cnt = {"i": 0}
+
+        def fn():
+            tr.step_slot(cnt["i"] & 1)
+            cnt["i"] += 1
     for _ in range(args.warmup):
         fn()
     torch.cuda.synchronize()
