@@ -617,9 +617,16 @@ __global__ void __launch_bounds__(256) topk_tau_kernel(const TopkArgs a) {
   for (int r = 0; r < a.k; ++r) {
     float bv = -INFINITY;
     int bp = -1;
-    for (int j = lane; j < a.n_chunks; j += 64) {
-      const float v = row[j];
-      if (v > bv) { bv = v; bp = j; }
+    for (int j0 = 0; j0 < a.n_chunks; j0 += 64 * 8) {       // eight independent LDS reads in flight per trip
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u * 64 + lane;
+        v[u] = j < a.n_chunks ? row[j] : -INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v[u] > bv) { bv = v[u]; bp = j0 + u * 64 + lane; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
