@@ -304,15 +304,16 @@ constexpr int kHS = 72;                         // bf16 row stride of an item ro
 constexpr int kStream16Lds = 2 * kChunk16 * kHS * 2;
 
 // begin(ut, user0) once per owned user tile; elem(ut, user0, item0, v) with the lane's four consecutive items of user user0 + li;
-// end(ut, user0, chunk) once per (user tile, chunk).
+// end(ut, user0, chunk) once per (user tile, chunk); need(chunk, user0[]) -> wave-uniform bool: false lets the wave skip the
+// chunk's tiles (it still helps staging the next chunk and meets the barriers).
 // SPLIT_E = false: bf16 table (rows copied as they are; 512 / 256-row chunks, two LDS buffers, one barrier per chunk).
 // SPLIT_E = true : fp32 table.  A chunk's rows are split into three exact bf16 planes e1 + e2 + e3 while they are staged
 //   (256-row chunks, ONE buffer of three planes = 110 KB: the next chunk waits in registers and is split / written between
 //   two barriers), and a logit takes the six products whose weight is above 2^-24 of the largest one - h1e1, h1e2, h2e1,
 //   h1e3, h2e2, h3e1 (smallest first) - twelve bf16 MFMAs per 16 x 16 tile against thirteen fp32 ones at twice the
 //   cycles each, with fp32-grade results (the dropped products are at the level of an fp32 rounding).
-template <int NU, bool SPLIT_E, class BEG, class ELEM, class END>
-__device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, ELEM&& elem, END&& end) {
+template <int NU, bool SPLIT_E, class BEG, class ELEM, class END, class NEED>
+__device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, ELEM&& elem, END&& end, NEED&& need) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NE = SPLIT_E ? 3 : 1;                  // bf16 planes of an item chunk
   constexpr int CH = SPLIT_E ? 256 : kChunk16;         // rows of a plane
@@ -432,10 +433,12 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
   int chunk = pw, cur = 0;
   __syncthreads();                       // (the zero fill above)
   if (chunk < a.n_chunks) { fetch(chunk); put(chunk, 0); }
+  bool work = chunk < a.n_chunks ? need(chunk, user0) : false;
   __syncthreads();
   for (; chunk < a.n_chunks; chunk += a.wg_per_group) {
     const int nxt = chunk + a.wg_per_group;
     if (nxt < a.n_chunks) fetch(nxt);
+    const bool work_next = nxt < a.n_chunks ? need(nxt, user0) : false;      // (its loads land under this chunk's tiles)
     const int64_t i0 = a.item_lo + (int64_t)chunk * a.crows;
     const int ntile = a.crows >> 4;
     // every row of the chunk is a rankable item (all chunks but the last one and, with exclude_pad, the one holding item 0):
@@ -492,7 +495,9 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
         elem(n, user0[n], item0, acc[n]);
       }
     };
-    if (full) {
+    if (!work) {
+      // nothing in this chunk can matter to this wave's users
+    } else if (full) {
       // software-pipelined over the item tiles: the MFMAs of tile t are in flight while tile t - 1 leaves its accumulators
       // and the fragments of tile t + 1 arrive from LDS (two tiles per trip: the accumulator sets alternate statically)
       f32x4 accA[NU], accB[NU];
@@ -514,8 +519,11 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
         tile_out(t, acc, true);
       }
     }
+    if (work) {
 #pragma unroll
-    for (int n = 0; n < NU; ++n) end(n, user0[n], chunk);
+      for (int n = 0; n < NU; ++n) end(n, user0[n], chunk);
+    }
+    work = work_next;
     if (SPLIT_E) {
       __syncthreads();                   // every wave is done reading the (single) buffer
       if (nxt < a.n_chunks) put(nxt, 0);
@@ -547,7 +555,8 @@ __global__ void __launch_bounds__(kWaves16 * 64) topk_max16_kernel(const TopkArg
         mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
         if (lane < 16 && u0 + lane < a.B) a.cmax[(int64_t)(u0 + lane) * a.n_chunks + chunk] = mm;
         m[n] = -INFINITY;
-      });
+      },
+      [&](int, const int*) { return true; });
 }
 
 template <int NU, bool SPLIT_E>
@@ -572,7 +581,18 @@ __global__ void __launch_bounds__(kWaves16 * 64) topk_collect16_kernel(const Top
           else a.ccnt[a.B] = 1;
         }
       },
-      [&](int, int, int) {});
+      [&](int, int, int) {},
+      // a chunk can hold a candidate of user u only if its maximum (pass A) reaches tau_u: about k chunks per user do, so a
+      // wave (32 users) multiplies ~1 chunk in 6 and skips the rest
+      [&](int chunk, const int* u0s) {
+        bool hit = false;
+#pragma unroll
+        for (int n = 0; n < NU; ++n) {
+          const int u = u0s[n] + li;
+          if (u < a.B) hit |= a.cmax[(int64_t)u * a.n_chunks + chunk] >= tau[n];
+        }
+        return __any(hit) != 0;
+      });
 }
 
 __global__ void __launch_bounds__(512) topk_max_kernel(const TopkArgs a) {
