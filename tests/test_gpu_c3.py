@@ -81,7 +81,7 @@ def test_c3_fused_step_equals_autograd_step_and_learns(c3):
     tr = srfrd_amd.FusedTrainer(m1, B, L, use_graph=True)
     opt = torch.optim.Adam(m2.parameters(), lr=1e-3, betas=(0.9, 0.98))
     crit = torch.nn.BCEWithLogitsLoss()
-    losses, hist = [], []
+    losses = []
     for step in range(3):
         l1 = tr.step(u, seq, rsq, pos, prs, neg, nrs)
         h, pl, nl = m2(u, seq, rsq, pos, prs, neg, nrs)
@@ -89,23 +89,26 @@ def test_c3_fused_step_equals_autograd_step_and_learns(c3):
         l2 = crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
         opt.zero_grad()
         l2.backward()
-        hist.append({k: p.grad.detach().clone() for k, p in m2.named_parameters()})
+        g0 = {k: p.grad.detach().clone() for k, p in m2.named_parameters()}
         opt.step()
         assert abs(float(l1) - float(l2.detach())) < 1e-5
         losses.append(float(l1))
+        if step == 0:
+            # ONE step from identical weights: every element within adam_tolerance of the autograd + torch.optim.Adam step.
+            # (Later steps are compared through the loss only: both runs scatter the item-table gradient with float atomics,
+            # so after step 0 their embeddings differ by an ulp here and there, a unit on its ReLU threshold then changes
+            # derivative in one run only, and at this size - 2.5 M ReLU units per step - some always do: elements whose
+            # summed gradient is small then take opposite Adam steps.  DESIGN section 2; tools/dp_parity.py restarts every
+            # step from recorded state for the same reason.)
+            sd1, sd2 = m1.state_dict(), m2.state_dict()
+            for k in sd1:
+                d = (sd1[k] - sd2[k]).abs().double().cpu()
+                bad = d > adam_tolerance([g0[k].cpu()])
+                assert not bool(bad.any()), (k, float(d[bad].max()), int(bad.sum()))
     assert losses[2] < losses[0]
     sd1, sd2 = m1.state_dict(), m2.state_dict()
-    # Both runs scatter the item-table gradient with float atomics, so after step 0 their embeddings differ by an ulp here
-    # and there; a unit sitting on its ReLU threshold then changes derivative in one run only and a whole sequence's dense
-    # gradient moves by far more than rounding.  At this batch size that shows up, in a few percent of the
-    # runs, as one or two elements whose Adam step flips: a handful of outliers bounded by the steps * lr an element can
-    # move at all is accepted, everything else is held to adam_tolerance.
-    for k in sd1:
-        d = (sd1[k] - sd2[k]).abs().double().cpu()
-        bad = d > adam_tolerance([g[k].cpu() for g in hist])
-        n_bad = int(bad.sum())
-        assert n_bad <= max(3, d.numel() // 5000), (k, float(d[bad].max()), n_bad)
-        assert n_bad == 0 or float(d[bad].max()) <= 3 * 1e-3 * 1.1, (k, float(d[bad].max()), n_bad)
+    for k in sd1:                                   # two more steps: at most 2 lr apart per step (opposite Adam steps)
+        assert float((sd1[k] - sd2[k]).abs().max()) <= 2 * 2 * 1e-3 * 1.1 + 1e-4, k
 
 
 def test_c3_untrained_hit_rate_is_chance(c3):
