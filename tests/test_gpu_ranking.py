@@ -204,3 +204,18 @@ def test_last_position_forward_equals_last_row_of_full_forward(kind, L):
     assert torch.equal(last[:, 0], full[:, -1])
     ho, _, _ = O.forward(cfg, sd, seq.cpu(), rsq.cpu(), None, None, None, None)
     assert float((last[:, 0].cpu() - ho[:, -1]).abs().max()) < 1e-4
+
+
+def test_topk_on_the_fp32_matrix_cores_agrees(monkeypatch):
+    """SRFRD_TOPK_FP32=1 keeps the fp32-matrix threshold passes (the path of item widths above 52): same indices, values
+    within fp32 rounding of the bf16-split path's."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, random_sd
+    cfg = O.Cfg("SRFRN", 6000, 20, 45, d_fake=5)
+    model = build_model(cfg, random_sd(cfg, 12)).eval()
+    batch = srfrd_amd.synthetic_batch(6000, 20, 40, seed=2, device="cpu")
+    seq, rsq = cuda(batch[1], batch[2])
+    i0, v0 = model.topk(None, seq, rsq, k=10)
+    monkeypatch.setenv("SRFRD_TOPK_FP32", "1")
+    i1, v1 = model.topk(None, seq, rsq, k=10)
+    assert torch.equal(i0, i1) and float((v0 - v1).abs().max()) < 1e-5
