@@ -96,16 +96,22 @@ def test_c4_geometry_fused_step_with_dropout_matches_oracle():
     assert_post_adam(model.state_dict(), sd, hist, cfg.D)
 
 
-@pytest.mark.parametrize("kind,L", [("SRFRN", 128), ("SASRec", 200)])
+@pytest.mark.parametrize("kind,L", [("SRFRN", 128), ("SASRec", 200), ("SASRec", 101), ("SRFU_B", 150), ("SRFRN", 207)])
 def test_long_fused_step_with_dropout_matches_oracle(kind, L):
-    """seq_len > 112 training: the row-owner forward in its training mode (dropout at the four sites, checkpoints written from
-    the transposed score layout, target logits, loss sums) feeding the global-scratch backward - two fused Adam steps with
-    dropout 0.5 against the oracle's steps with the same masks."""
+    """seq_len > 100 training: the forward (first generation up to 112, the row-owner kernel in its training mode above:
+    dropout at the four sites, checkpoints written from the transposed score layout, target logits, loss sums) feeding the
+    row-chunked backward - two fused Adam steps with dropout 0.5 against the oracle's steps with the same masks; lengths that
+    are not multiples of 4 or 16 and the largest one the kernels take (207: 13 row tiles, five chunks) included."""
     import srfrd_amd
     from tests.gpu_util import build_model, cuda, random_sd
     from tests.helpers import assert_post_adam, oracle_step_with_grads
     I, B, base = 300, 5, 77
-    cfg = O.Cfg(kind, I, L, 50, dropout=0.5) if kind == "SASRec" else O.Cfg(kind, I, L, 45, d_fake=5, dropout=0.5)
+    if kind == "SASRec":
+        cfg = O.Cfg(kind, I, L, 50, dropout=0.5)
+    elif kind == "SRFRN":
+        cfg = O.Cfg(kind, I, L, 45, d_fake=5, dropout=0.5)
+    else:
+        cfg = O.Cfg(kind, I, L, 50, n_labels=3, dropout=0.5)
     sd = random_sd(cfg, 3)
     model = build_model(cfg, {k: v.clone() for k, v in sd.items()}).train()
     tr = srfrd_amd.FusedTrainer(model, batch_size=B, seq_len=L, lr=1e-3, betas=(0.9, 0.98), seed=base, use_graph=False)
