@@ -236,3 +236,46 @@ def test_custom_ops_pass_opcheck_and_carry_autograd():
                           test_utils=("test_schema", "test_faketensor"))
     cand = torch.randint(1, 91, (6, 11), device="cuda")
     torch.library.opcheck(torch.ops.srfrd.predict_logits.default, (h, cand, model.user_labels(rsq), key), test_utils=("test_schema", "test_faketensor"))
+
+
+@pytest.mark.parametrize("kind,L,B", [("SASRec", 1, 3), ("SRFRN", 5, 1), ("SRFU_R", 16, 3), ("SASRec", 17, 3), ("SRFR", 50, 2)])
+def test_edge_shapes_and_ragged_sequences(kind, L, B):
+    """Ragged and degenerate inputs: a sequence that is all padding, one with a single real item (left-padded, as the
+    reference's sampler produces them), a full one; seq_len 1 / 5 / 16 / 17 (below, at and just past a 16-row tile), batch 1.
+    Forward (hidden states, target logits), predict and one fused training step against the oracle."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, maxerr, random_sd
+    from tests.helpers import assert_post_adam, oracle_step_with_grads
+    I = 60
+    if kind == "SASRec":
+        cfg = O.Cfg(kind, I, L, 50)
+    elif kind in ("SRFR", "SRFRN"):
+        cfg = O.Cfg(kind, I, L, 45, d_fake=5)
+    else:
+        cfg = O.Cfg(kind, I, L, 50, n_labels=11)
+    sd = random_sd(cfg, 9)
+    g = torch.Generator().manual_seed(L * 7 + B)
+    seq = torch.randint(1, I + 1, (B, L), generator=g)
+    pos = torch.randint(1, I + 1, (B, L), generator=g)
+    neg = torch.randint(1, I + 1, (B, L), generator=g)
+    rsq, prs, nrs = (torch.randint(1, 3, (B, L), generator=g) for _ in range(3))
+    if B >= 2:                                       # sequence 0: nothing but padding
+        seq[0] = 0; pos[0] = 0; neg[0] = 0; rsq[0] = 0; prs[0] = 0; nrs[0] = 0
+    if B >= 3 and L > 1:                             # sequence 1: one real interaction, left-padded
+        seq[1, :-1] = 0; pos[1, :-1] = 0; neg[1, :-1] = 0; rsq[1, :-1] = 0; prs[1, :-1] = 0; nrs[1, :-1] = 0
+    batch = (seq, rsq, pos, prs, neg, nrs)
+    model = build_model(cfg, {k: v.clone() for k, v in sd.items()}).eval()
+    with torch.no_grad():
+        h, pl, nl = model(None, *cuda(*batch))
+        cand = torch.arange(1, I + 1)
+        pr = model.predict(None, *cuda(seq, rsq), cand.cuda())
+    ho, plo, nlo = O.forward(cfg, sd, *batch)
+    assert maxerr(h, ho) < 1e-4 and maxerr(pl, plo) < 1e-4 and maxerr(nl, nlo) < 1e-4
+    assert maxerr(pr.reshape(B, -1), O.predict(cfg, sd, seq, rsq, cand).reshape(B, -1)) < 1e-4
+    model.train()
+    tr = srfrd_amd.FusedTrainer(model, batch_size=B, seq_len=L, lr=1e-3, betas=(0.9, 0.98), seed=1, use_graph=False)
+    opt = O.Adam(sd)
+    loss = tr.step(None, *cuda(*batch))
+    loss_o, g_o = oracle_step_with_grads(cfg, sd, opt, batch, train=False)
+    assert abs(float(loss.cpu()) - float(loss_o)) < 1e-4
+    assert_post_adam(model.state_dict(), sd, [g_o], cfg.D)
