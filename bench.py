@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-metric-parity", action="store_true", help="skip the end-to-end HR@10 run (profiling passes: keeps the "
                     "per-kernel averages of the profile free of that run's small launches)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 / C5 side measurements (config.other_workloads_ms)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="exploration only; the contract line is C2")
     ap.add_argument("--deterministic", action="store_true", help="deterministic item-table scatter (sort + ordered sums) instead of float atomics")
     ap.add_argument("--autograd", action="store_true", help="exploration: time the module-level drop-in path (model(...) -> BCE -> "
@@ -209,17 +210,7 @@ def main():
 
     import srfrd_amd
     cfg = WORKLOADS[args.workload]
-    torch.manual_seed(0)                      # identical init on every rank (replicated parameters)
-    if cfg["kind"] == "SASRec":
-        model = srfrd_amd.SASRec(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
-    elif cfg["kind"] == "SRFRN":
-        model = srfrd_amd.SRFRN(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["fake"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
-    else:
-        model = srfrd_amd.SRFU_B(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["labels"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
-    for _, p in model.named_parameters():     # reference trainer.py:364-369
-        if p.dim() >= 2:
-            torch.nn.init.xavier_normal_(p.data)
-    model = model.to(dev).train()
+    model = build_model(cfg, dev)
     B, L = cfg["batch"], cfg["seq_len"]
     if args.predict or args.autograd or args.workload != "C2":
         return explore(args, cfg, model, dev, rank)
@@ -298,13 +289,52 @@ def main():
                 out["config"]["metric_parity"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
+        if world == 1 and not args.no_secondary:
+            del tr
+            torch.cuda.empty_cache()
+            out["config"]["other_workloads_ms"] = other_workloads(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def explore(args, cfg, model, dev, rank):
+def build_model(cfg, dev):
+    import srfrd_amd
+    torch.manual_seed(0)                      # identical init on every rank (replicated parameters)
+    if cfg["kind"] == "SASRec":
+        model = srfrd_amd.SASRec(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
+    elif cfg["kind"] == "SRFRN":
+        model = srfrd_amd.SRFRN(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["fake"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
+    else:
+        model = srfrd_amd.SRFU_B(cfg["n_items"], cfg["seq_len"], cfg["hidden"], cfg["labels"], cfg["dropout"], cfg["blocks"], cfg["heads"], dev)
+    for _, p in model.named_parameters():     # reference trainer.py:364-369
+        if p.dim() >= 2:
+            torch.nn.init.xavier_normal_(p.data)
+    return model.to(dev).train()
+
+
+def other_workloads(dev):
+    """The other BASELINE configs, measured in the same run on the same GPU (N = 1 only; never the contract value): ms per
+    512-sequence train step, ms per 512-user exact top-10 over the catalog (forward included)."""
+    import argparse
+    out = {}
+    plan = [("C3", False, 60), ("C4", False, 60), ("C5", False, 30), ("C2", True, 100), ("C5", True, 40), ("C5_bf16_table", True, 40)]
+    for name, predict, steps in plan:
+        key = f"{name}:{'top10' if predict else 'train'}"
+        try:
+            a = argparse.Namespace(predict=predict, autograd=False, no_graph=False, deterministic=False, steps=steps, warmup=15,
+                                   workload=name)
+            model = build_model(WORKLOADS[name], dev)
+            out[key] = round(explore(a, WORKLOADS[name], model, dev, 0, quiet=True), 4)
+            del model
+            torch.cuda.empty_cache()
+        except Exception as e:              # never lose the contract line to a side measurement
+            out[key] = repr(e)
+    return out
+
+
+def explore(args, cfg, model, dev, rank, quiet=False):
     """Non-contract measurements of the other BASELINE configs (train step, or forward + full-catalog top-10)."""
     import srfrd_amd
     B, L = cfg["batch"], cfg["seq_len"]
@@ -346,6 +376,8 @@ def explore(args, cfg, model, dev, rank):
         fn()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if quiet:
+        return el / args.steps * 1e3
     print(json.dumps({"workload": args.workload, "mode": "predict_top10" if args.predict else ("train_step_autograd_path" if args.autograd else "train_step"),
                       "kind": cfg["kind"], "sequences_per_s": B * args.steps / el, "ms_per_step": el / args.steps * 1e3,
                       "batch": B, "seq_len": L, "n_items": cfg["n_items"], "item_table": "bf16 shadow" if cfg.get("bf16_table") else "fp32",
