@@ -241,6 +241,78 @@ class FusedTrainer:
         self.packed = self.model.pack_weights()
         self._fresh = True
 
+    # ---- optimizer state in torch.optim.Adam's own format ------------------------------------------------------------
+    def _moments_full(self):
+        """(exp_avg, exp_avg_sq) over the whole flat vector; in the sharded form every rank holds a slice: all-gathered here
+        (a collective - every rank must make the call)."""
+        if self.mode != "sharded":
+            return self.m, self.v
+        out = []
+        for part in (self.m, self.v):
+            full = torch.zeros(self.ex.n_pad, device=part.device, dtype=torch.float32)
+            full[self.ex.i0:self.ex.i1] = part
+            out.append(self.ex.all_gather(full))
+        return out[0], out[1]
+
+    def state_dict(self):
+        """The optimizer state as ``torch.optim.Adam(model.parameters(), lr, betas, eps).state_dict()`` would hold it after
+        the same steps (per parameter ``step``, ``exp_avg``, ``exp_avg_sq``; one param group) - loadable by either side -
+        plus ``"srfrd"``: the dropout base seed, so that a resumed run draws the masks the uninterrupted one would have.
+        The reference saves the model only (trainer.py:409-411); this is what resuming TRAINING needs on top."""
+        m, v = self._moments_full()
+        params = list(self.model.parameters())
+        off = {id(p): o for p, o in self.model._slots}
+        state = {}
+        for i, p in enumerate(params):
+            o, n = off[id(p)], p.numel()
+            state[i] = {"step": torch.tensor(float(self.steps_done)),
+                        "exp_avg": m[o:o + n].view(p.shape).clone(), "exp_avg_sq": v[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group],
+                "srfrd": {"seed": int(self.state[1].item()), "steps_done": int(self.steps_done)}}
+
+    def load_state_dict(self, sd):
+        """Inverse of state_dict(); also takes the state_dict of a torch.optim.Adam that stepped the same model's
+        parameters (the module-level path), so a run can move between the two.  Hyper-parameters come from the dict."""
+        params = list(self.model.parameters())
+        off = {id(p): o for p, o in self.model._slots}
+        group = sd["param_groups"][0]
+        if any(group.get(k) for k in ("weight_decay", "amsgrad", "maximize")):
+            raise ValueError("FusedTrainer implements plain Adam (no weight decay / amsgrad / maximize)")
+        if list(group["params"]) != list(range(len(params))):
+            raise ValueError("optimizer state does not cover this model's parameters in order")
+        steps = {int(float(st["step"])) for st in sd["state"].values()}
+        if len(steps) > 1:
+            raise ValueError("parameters with different step counts")
+        self.lr, self.betas, self.eps = float(group["lr"]), (float(group["betas"][0]), float(group["betas"][1])), float(group["eps"])
+        dev = self.flat.device
+        m = torch.zeros(self.ex.n_pad if self.mode == "sharded" else self.n_flat, device=dev, dtype=torch.float32)
+        v = torch.zeros_like(m)
+        for i, p in enumerate(params):
+            st = sd["state"].get(i)
+            if st is None:
+                continue                                   # (a parameter that never received a gradient: zero moments)
+            o, n = off[id(p)], p.numel()
+            m[o:o + n] = st["exp_avg"].to(device=dev, dtype=torch.float32).reshape(-1)
+            v[o:o + n] = st["exp_avg_sq"].to(device=dev, dtype=torch.float32).reshape(-1)
+        if self.mode == "sharded":
+            self.m.copy_(m[self.ex.i0:self.ex.i1]); self.v.copy_(v[self.ex.i0:self.ex.i1])
+        else:
+            self.m.copy_(m); self.v.copy_(v)
+        self.steps_done = steps.pop() if steps else 0
+        extra = sd.get("srfrd") or {}
+        seed = int(extra.get("seed", int(self.state[1].item()))) & 0x7FFFFFFF
+        self.state.zero_()                                 # (ticket words of the fused tail included)
+        self.state[0] = self.steps_done
+        self.state[1] = seed
+        # step size, bias correction and dropout seed of the NEXT step (t = steps_done + 1), as after an uninterrupted run.
+        # (The captured graphs bake lr / betas in as launch arguments: they are re-captured.)
+        check(_lib.lib().srfrd_step_begin(ptr(self.state), self.lr, self.betas[0], self.betas[1], self._stream()), "srfrd_step_begin")
+        self._graph_a = self._graph_b = self._graph_f = self._graph_u = None
+        self._fresh = False
+
     def _check_slot(self, slot: int = 0):
         ids, kind = self.ids_ring[slot], self.lay.kind
         n = self.B * self.L

@@ -360,3 +360,65 @@ def test_deterministic_table_scatter_is_bitwise_repeatable():
     assert le == la and torch.equal(fe, fa)                                   # eager == graph replay, bit for bit
     lc, fc = run(False)
     assert max(abs(x - y) for x, y in zip(la[:2], lc[:2])) < 1e-6            # same arithmetic up to summation order
+
+
+def test_trainer_state_dict_resumes_bitwise_and_interoperates_with_torch_adam():
+    """FusedTrainer.state_dict() / load_state_dict(): (1) a run interrupted after two steps and resumed in a fresh model +
+    trainer takes a third step bit-identical to the uninterrupted run's (dropout on: the mask seed sequence continues;
+    deterministic scatter, so the comparison can be bitwise); (2) the dict IS a torch.optim.Adam state_dict: torch's Adam
+    loads it, and a trainer loads the state of a torch Adam that stepped the module path, the next fused step then matching
+    the next autograd step."""
+    import copy
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, random_sd
+    from tests.helpers import adam_tolerance
+    cfg = O.Cfg("SRFRN", 300, 20, 45, d_fake=5, dropout=0.5)
+    sd0 = random_sd(cfg, 5)
+    batches = [cuda(*srfrd_amd.synthetic_batch(300, 20, 8, seed=70 + i, device="cpu")) for i in range(3)]
+    # ---- (1) interrupted and resumed
+    mA = build_model(cfg, {k: v.clone() for k, v in sd0.items()}).train()
+    tA = srfrd_amd.FusedTrainer(mA, 8, 20, seed=9, use_graph=True, deterministic=True)
+    for i in range(2):
+        tA.step(*batches[i])
+    ckpt_model = {k: v.detach().clone() for k, v in mA.state_dict().items()}
+    ckpt_opt = copy.deepcopy(tA.state_dict())
+    tA.step(*batches[2])
+    mB = build_model(cfg, {k: v.clone().cpu() for k, v in ckpt_model.items()}).train()
+    tB = srfrd_amd.FusedTrainer(mB, 8, 20, seed=12345, use_graph=True, deterministic=True)      # (its own seed is overwritten)
+    tB.load_state_dict(ckpt_opt)
+    assert tB.steps_done == 2
+    tB.step(*batches[2])
+    for k, v in mA.state_dict().items():
+        assert torch.equal(v, mB.state_dict()[k]), k
+    # ---- (2a) torch's Adam takes the dict
+    opt = torch.optim.Adam(mB.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    opt.load_state_dict(tB.state_dict())
+    st = opt.state_dict()["state"]
+    assert len(st) == len(list(mB.parameters())) and all(float(s["step"]) == 3.0 for s in st.values())
+    # ---- (2b) a trainer takes torch Adam's state (dropout off for an element-wise comparison)
+    cfg0 = O.Cfg("SRFRN", 300, 20, 45, d_fake=5)
+    mC = build_model(cfg0, {k: v.clone() for k, v in sd0.items()}).train()
+    optC = torch.optim.Adam(mC.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    crit = torch.nn.BCEWithLogitsLoss()
+
+    def autograd_step(model, o, batch):
+        h, pl, nl = model(*batch)
+        idx = torch.where(batch[3] != 0)
+        loss = crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
+        o.zero_grad()
+        loss.backward()
+        g = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        o.step()
+        return g
+
+    for i in range(2):
+        autograd_step(mC, optC, batches[i])
+    mD = build_model(cfg0, {k: v.detach().clone().cpu() for k, v in mC.state_dict().items()}).train()
+    tD = srfrd_amd.FusedTrainer(mD, 8, 20, use_graph=False)
+    tD.load_state_dict(optC.state_dict())
+    g = autograd_step(mC, optC, batches[2])
+    tD.step(*batches[2])
+    sdC, sdD = mC.state_dict(), mD.state_dict()
+    for k in sdC:
+        d = (sdC[k] - sdD[k]).abs().double().cpu()
+        assert not bool((d > adam_tolerance([g[k].cpu()])).any()), k
