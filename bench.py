@@ -385,7 +385,10 @@ def explore(args, cfg, model, dev, rank, quiet=False):
 
 
 def time_kernels(tr, batches, steps):
-    """Average duration (ms) of each launch, bracketed by events on the stream the launches go to."""
+    """Average duration (ms) of each launch, bracketed by events on the stream the launches go to.  The launches are eager
+    here (one host call each), so an interval also holds whatever time the host took to issue the next launch when the GPU
+    had run dry: a few untimed iterations first, and an iteration whose interval exceeds 3x the median of its kernel is a
+    host stall, not a launch, and is left out of that kernel's average."""
     import ctypes as C
     from srfrd_amd import _lib
     from srfrd_amd._lib import check, ptr
@@ -397,6 +400,8 @@ def time_kernels(tr, batches, steps):
         names.append("srfrd_loss_finalize")
     lib = _lib.lib()
     acc = {n: 0.0 for n in names}
+    lead = 5
+    steps += lead
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(steps)]
     # re-use the trainer's own enqueue code, but with an event between launches: wrap the C entry points
     orig = {n: getattr(lib, n) for n in names}
@@ -423,10 +428,11 @@ def time_kernels(tr, batches, steps):
     finally:
         for n in names:
             setattr(lib, n, orig[n])
-    for i in range(steps):
-        for k, n in enumerate(names):
-            acc[n] += ev[i][k].elapsed_time(ev[i][k + 1])
-    return {n: acc[n] / steps for n in names}
+    for k, n in enumerate(names):
+        ts = sorted(ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(lead, steps))
+        ts = [t for t in ts if t <= 3.0 * ts[len(ts) // 2]]
+        acc[n] = sum(ts) / len(ts)
+    return acc
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@ enum srfrd_kind {               /* reference classes, SRFR_model.py */
 
 enum srfrd_error {
   SRFRD_E_ARG = -1,             /* bad argument (null pointer, size out of range) */
-  SRFRD_E_UNSUPPORTED = -2,     /* configuration outside what the fused kernels cover (D > 64, heads != 1, L too long for LDS) */
+  SRFRD_E_UNSUPPORTED = -2,     /* configuration outside what the fused kernels cover (D > 64, L too long for LDS and no scratch given) */
   SRFRD_E_DEVICE = -3           /* not a gfx950 device / LDS attribute could not be set */
 };
 
@@ -95,7 +95,7 @@ int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64_t* fwd_flo
 
 /* [host] floats of the forward's `save_aux` checkpoint buffer for (B, L): per block and sequence the FFN hidden
  * activation relu(drop(.)), the attention output P v, the scaled queries, the keys and the values (L, D each) and the
- * attention probabilities (L, LP = L rounded up to 16), the latter sign-coded with the attention-dropout mask (a
+ * attention probabilities (n_heads, L, LP = L rounded up to 16), the latter sign-coded with the attention-dropout mask (a
  * dropped entry is stored negated); sequence-major (all blocks of one sequence are contiguous). */
 int64_t srfrd_aux_floats(const srfrd_layout* lay, int B, int L);
 

@@ -131,8 +131,8 @@ def keep_mask(seed: int, site: int, b0: int, B: int, R: int, C: int, p: float) -
 SITE_EMB = 0
 
 
-def site_attn(i):
-    return 1 + 3 * i
+def site_attn(i, head=0):
+    return 1 + 3 * i + 1024 * head
 
 
 def site_ffn1(i):
@@ -222,7 +222,7 @@ def encoder_block(cfg: Cfg, sd, i, x, keep, m_attn=None, m_f1=None, m_f2=None, t
     if taps is not None:
         taps[f"qn{i}"], taps[f"q{i}"], taps[f"k{i}"], taps[f"v{i}"], taps[f"p{i}"] = qn, q, k, v, p
     if m_attn is not None:
-        p = p * m_attn.unsqueeze(1)          # same mask for every head (H == 1 in the product path)
+        p = p * (m_attn if m_attn.dim() == 4 else m_attn.unsqueeze(1))      # (B,H,L,L): one mask per head
     o = (p @ vh).transpose(1, 2).reshape(B, L, D)
     o = o @ sd[pre + "out_proj.weight"].T + sd[pre + "out_proj.bias"]
     h1 = qn + o
@@ -256,7 +256,7 @@ def forward(cfg: Cfg, sd, input_ids, fake_ids, pos_ids=None, pos_fake=None, neg_
             km = keep_mask
         masks = {SITE_EMB: km(seed, SITE_EMB, b0, B, L, D, p)}
         for i in range(cfg.num_blocks):
-            masks[site_attn(i)] = km(seed, site_attn(i), b0, B, L, L, p)
+            masks[site_attn(i)] = torch.stack([km(seed, site_attn(i, h), b0, B, L, L, p) for h in range(cfg.num_heads)], dim=1)
             masks[site_ffn1(i)] = km(seed, site_ffn1(i), b0, B, L, D, p)
             masks[site_ffn2(i)] = km(seed, site_ffn2(i), b0, B, L, D, p)
     x = embed(cfg, sd, input_ids, fake_ids, masks)

@@ -82,7 +82,7 @@ __device__ __forceinline__ int clamp_id(int64_t v, int hi) {
 // Compact, all-int32 view of srfrd_layout passed to the kernels (the full descriptor with its 8 x 12 int64 block
 // table costs hundreds of SGPRs; block offsets are affine in the block index, so they are recomputed instead).
 struct Dims {
-  int kind, d_item, d_fake, D, d_out, n_labels, n_blocks, n_items;
+  int kind, d_item, d_fake, D, d_out, n_labels, n_blocks, n_items, n_heads;
   int off_pos, off_side, blk0, blk_stride, off_lc_w, off_lc_b, off_ll_w, off_ll_b, n_dense;
 };
 struct BlkOff {
@@ -134,6 +134,11 @@ struct MatT {           // element (r, c) of the transpose of a row-major LDS ma
   const lds_f* p;
   int ld;
   __device__ __forceinline__ float operator()(int r, int c) const { return p[c * ld + r]; }
+};
+struct MatCols {        // row-major LDS matrix with the columns outside [c0, c1) read as zero: one attention head's slice
+  const lds_f* p;       // of q / do as the A operand of a full-width product (multi-head path of the generic kernels)
+  int ld, c0, c1;
+  __device__ __forceinline__ float operator()(int r, int c) const { return (c >= c0 && c < c1) ? p[r * ld + c] : 0.f; }
 };
 struct MatTPos {        // transpose of an LDS matrix with negative entries read as zero: the sign-coded attention
   const lds_f* p;       // probabilities (dropped entries stored negated) read as the kept ones

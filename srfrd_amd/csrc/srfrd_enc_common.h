@@ -48,16 +48,16 @@ struct EncArgs {
 // Checkpoint layout: SEQUENCE-major.  Everything the backward reads back for sequence b is contiguous per buffer -
 // save_x: (nb + 1) blocks of [L][D] at b * (nb + 1) * L * D; save_h1: nb blocks at b * nb * L * D; save_aux
 // (srfrd_aux_floats): nb blocks of aux_seq_floats at b * nb * aux_seq_floats, each the planes r, o, q, k, v [L][D] and
-// Pm [L][LP].  (A block-major layout put the ten planes a workgroup touches per block 10 MB apart at BASELINE
+// Pm [H][L][LP] (one probability block per attention head).  (A block-major layout put the ten planes a workgroup touches per block 10 MB apart at BASELINE
 // configs[3]: every first access of a phase was a TLB miss on the sequence's critical path.)
-__host__ __device__ __forceinline__ int64_t aux_seq_floats(int L, int LP, int D) { return 5ll * L * D + (int64_t)L * LP; }
+__host__ __device__ __forceinline__ int64_t aux_seq_floats(int L, int LP, int D, int H = 1) { return 5ll * L * D + (int64_t)H * L * LP; }
 __host__ __device__ __forceinline__ int64_t x_off(int i, int b, int nb, int L, int D) { return ((int64_t)b * (nb + 1) + i) * L * D; }
 __host__ __device__ __forceinline__ int64_t h1_off(int i, int b, int nb, int L, int D) { return ((int64_t)b * nb + i) * L * D; }
 struct AuxOff {
   int64_t r, o, q, k, v, p;
 };
-__host__ __device__ __forceinline__ AuxOff aux_off(int i, int b, int nb, int L, int LP, int D) {
-  const int64_t blk = ((int64_t)b * nb + i) * aux_seq_floats(L, LP, D), plane = (int64_t)L * D;
+__host__ __device__ __forceinline__ AuxOff aux_off(int i, int b, int nb, int L, int LP, int D, int H = 1) {
+  const int64_t blk = ((int64_t)b * nb + i) * aux_seq_floats(L, LP, D, H), plane = (int64_t)L * D;
   AuxOff f;
   f.r = blk;
   f.o = blk + plane;
@@ -228,13 +228,13 @@ __device__ __forceinline__ void tap(const EncArgs& a, int b, int slot, const lds
                      const int64_t* neg_ids, const int64_t* neg_fake, int B, int L, double dropout_p, uint32_t seed,
                      const uint32_t* seed_dev, int64_t seq_index0) {
   if (!lay || !item_table || !dense || !packed || !input_ids || B <= 0 || L <= 0) return SRFRD_E_ARG;
-  if (lay->D > SRFRD_MAX_D || lay->n_heads != 1 || lay->n_blocks > SRFRD_MAX_BLOCKS) return SRFRD_E_UNSUPPORTED;
+  if (lay->D > SRFRD_MAX_D || lay->n_heads < 1 || lay->D % lay->n_heads != 0 || lay->n_blocks > SRFRD_MAX_BLOCKS) return SRFRD_E_UNSUPPORTED;
   if (L > lay->max_len) return SRFRD_E_ARG;
   if (dropout_p < 0.0 || dropout_p >= 1.0) return SRFRD_E_ARG;
   if (lay->kind == SRFRD_SRFRN && ((pos_ids && !pos_fake) || (neg_ids && !neg_fake))) return SRFRD_E_ARG;
   Dims& d = a.dm;
   d.kind = lay->kind; d.d_item = lay->d_item; d.d_fake = lay->d_fake; d.D = lay->D; d.d_out = lay->d_out;
-  d.n_labels = lay->n_labels; d.n_blocks = lay->n_blocks; d.n_items = lay->n_items;
+  d.n_labels = lay->n_labels; d.n_blocks = lay->n_blocks; d.n_items = lay->n_items; d.n_heads = lay->n_heads;
   d.off_pos = (int)lay->off_pos; d.off_side = (int)lay->off_side;
   d.blk0 = lay->n_blocks > 0 ? (int)lay->blk[0].ln1_w : 0;
   d.blk_stride = blk_stride_of(lay->D);

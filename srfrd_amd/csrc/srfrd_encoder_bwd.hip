@@ -50,7 +50,7 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table
 #else
   const bool taps = dbg != nullptr;
 #endif
-  if (lds > kLdsLimit && !taps && lay->D == 50 &&
+  if (lds > kLdsLimit && !taps && lay->D == 50 && lay->n_heads == 1 &&
       getenv("SRFRD_NO_SLOTS") == nullptr && getenv("SRFRD_GENERIC") == nullptr) {
     // a long sequence (fused training step or autograd backward): the slot-placed, query-chunked LDS-resident kernel where
     // one is built, the row-chunked one otherwise
@@ -78,12 +78,12 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table
     if (!scratch || scratch_floats < stride * grid) return SRFRD_E_UNSUPPORTED;
     a.scratch = scratch;
     a.scratch_stride = stride;
-    const bool c4 = lay->kind == SRFRD_SASREC && lay->D == 50 && L == 100 && pos_ids && neg_ids && fused_bce && !d_hidden &&
+    const bool c4 = lay->kind == SRFRD_SASREC && lay->D == 50 && lay->n_heads == 1 && L == 100 && pos_ids && neg_ids && fused_bce && !d_hidden &&
                     dropout_p > 0.0 && !dbg && getenv("SRFRD_NO_LSPEC") == nullptr && getenv("SRFRD_GENERIC") == nullptr;
     return srfrd_long_launch_bwd(&a, grid, 512, c4 ? 1 : 0, stream);
   }
   const int threads = env_threads("SRFRD_BWD_THREADS", 512);
-  const bool spec = getenv("SRFRD_GENERIC") == nullptr && threads == 512 && lay->D == 50;
+  const bool spec = getenv("SRFRD_GENERIC") == nullptr && threads == 512 && lay->D == 50 && lay->n_heads == 1;
   if (spec && g.LP == 64 && L == 50 && getenv("SRFRD_NO_LSPEC") == nullptr)
   {
     const bool train = pos_ids && neg_ids && fused_bce && !d_hidden && dropout_p > 0.0 && !dbg && getenv("SRFRD_NO_TSPEC") == nullptr;

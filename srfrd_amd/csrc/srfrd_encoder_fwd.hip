@@ -55,7 +55,7 @@ extern "C" int srfrd_fwd_rows_launch(const void* args, int kind_variant, int mod
 extern "C" int64_t srfrd_aux_floats(const srfrd_layout* lay, int B, int L) {
   if (!lay || B <= 0 || L <= 0) return SRFRD_E_ARG;
   const Geom g = make_geom(L, lay->D);
-  return (int64_t)lay->n_blocks * B * aux_seq_floats(L, g.LP, lay->D);
+  return (int64_t)lay->n_blocks * B * aux_seq_floats(L, g.LP, lay->D, lay->n_heads);
 }
 
 extern "C" int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64_t* fwd_floats, int64_t* bwd_floats) {
@@ -126,7 +126,7 @@ static int encoder_fwd_impl(const srfrd_layout* lay, const void* item_table, con
   // 7 or 4 row tiles it runs one or two waves per SIMD and their dependent chains are exposed; SRFRD_ROWS_ALWAYS selects it
   // anyway, for tests.)
   const bool rows_wanted = lds > kLdsLimit || getenv("SRFRD_ROWS_ALWAYS") != nullptr;
-  if (rows_wanted && !dbg && lay->D == 50 && getenv("SRFRD_NO_ROWS") == nullptr && getenv("SRFRD_GENERIC") == nullptr) {
+  if (rows_wanted && !dbg && lay->D == 50 && lay->n_heads == 1 && getenv("SRFRD_NO_ROWS") == nullptr && getenv("SRFRD_GENERIC") == nullptr) {
     int kv = -1;
     if (lay->kind == SRFRD_SASREC) kv = 0;
     else if (lay->kind == SRFRD_SRFR && lay->d_item == 45) kv = 1;
@@ -151,7 +151,8 @@ static int encoder_fwd_impl(const srfrd_layout* lay, const void* item_table, con
   if (grid > B) grid = B;
   // 8 waves per workgroup measured fastest for the forward (95 vs 118 us at C2 with 4 waves)
   const int threads = env_threads("SRFRD_FWD_THREADS", 512);
-  const bool spec = getenv("SRFRD_GENERIC") == nullptr && lay->D == 50;
+  // (several attention heads: the generic instantiation only)
+  const bool spec = getenv("SRFRD_GENERIC") == nullptr && lay->D == 50 && lay->n_heads == 1;
   if (spec && threads == 512 && g.LP == 64 && L == 50 && getenv("SRFRD_NO_LSPEC") == nullptr)
   {
     const bool train = pos_ids && neg_ids && save_x && loss_part && dropout_p > 0.0 && !dbg && getenv("SRFRD_NO_TSPEC") == nullptr;

@@ -20,7 +20,7 @@ SRFRD_HD uint32_t fmix32(uint32_t h) {
 }
 
 enum { SITE_EMB = 0 };
-SRFRD_HD int site_attn(int blk) { return 1 + 3 * blk; }
+SRFRD_HD int site_attn(int blk, int head = 0) { return 1 + 3 * blk + 1024 * head; }   // (one mask per attention head)
 SRFRD_HD int site_ffn1(int blk) { return 2 + 3 * blk; }
 SRFRD_HD int site_ffn2(int blk) { return 3 + 3 * blk; }
 

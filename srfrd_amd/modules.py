@@ -160,9 +160,8 @@ class _SRFRDBase(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("srfrd_amd modules compute only on a ROCm GPU (device 'cuda'); move the model with "
                                ".to('cuda'). There is no CPU fallback.")
-        if lay.D > _lib.MAX_D or lay.n_heads != 1:
-            raise NotImplementedError("the fused MI355X kernels cover hidden width <= 64 and num_heads == 1 "
-                                      f"(got width {lay.D}, heads {lay.n_heads})")
+        if lay.D > _lib.MAX_D:
+            raise NotImplementedError(f"the fused MI355X kernels cover hidden width <= 64 (got width {lay.D})")
         slots = [(table, 0)] + [(p, self.n_table_pad + off) for p, off in self._dense_params()]
         flat = self._flat
         if flat is not None and flat.device == dev:

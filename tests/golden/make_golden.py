@@ -55,15 +55,15 @@ def make_inputs(seed, I=I, L=L, B=B):
     return seq, rsq, pos, prs, neg, nrs
 
 
-def build(kind, dropout):
+def build(kind, dropout, nh=NH):
     if kind == "SASRec":
-        return ref.SASRec(I, L, D_ITEM + D_FAKE, dropout, NB, NH, "cpu")
+        return ref.SASRec(I, L, D_ITEM + D_FAKE, dropout, NB, nh, "cpu")
     if kind == "SRFR":
-        return ref.SRFR(I, L, D_ITEM, D_FAKE, dropout, NB, NH, "cpu")
+        return ref.SRFR(I, L, D_ITEM, D_FAKE, dropout, NB, nh, "cpu")
     if kind == "SRFRN":
-        return ref.SRFRN(I, L, D_ITEM, D_FAKE, dropout, NB, NH, "cpu")
+        return ref.SRFRN(I, L, D_ITEM, D_FAKE, dropout, NB, nh, "cpu")
     nl = {"SRFU_B": 3, "SRFU_F": L + 1, "SRFU_R": 11}[kind]
-    return getattr(ref, kind)(I, L, D_ITEM + D_FAKE, nl, dropout, NB, NH, "cpu")
+    return getattr(ref, kind)(I, L, D_ITEM + D_FAKE, nl, dropout, NB, nh, "cpu")
 
 
 def trainer_init(model):
@@ -84,11 +84,16 @@ def t64(a):
     return torch.from_numpy(a)
 
 
-def main():
+HEAD_CASES = (("SASRec", 2), ("SRFRN", 5), ("SRFU_B", 2))      # num_heads > 1: <kind>_h<heads>.npz (--heads)
+
+
+def main(cases=None):
     torch.set_num_threads(1)
-    for k_i, kind in enumerate(["SASRec", "SRFR", "SRFRN", "SRFU_B", "SRFU_F", "SRFU_R"]):
-        torch.manual_seed(1234 + k_i)
-        model = build(kind, 0.0)
+    all_kinds = ["SASRec", "SRFR", "SRFRN", "SRFU_B", "SRFU_F", "SRFU_R"]
+    for kind, nh in (cases or [(k, NH) for k in all_kinds]):
+        k_i = all_kinds.index(kind)
+        torch.manual_seed(1234 + k_i + 100 * (nh - 1))
+        model = build(kind, 0.0, nh)
         trainer_init(model)
         seq, rsq, pos, prs, neg, nrs = make_inputs(7 + k_i)
         out = {"seq": seq, "rsq": rsq, "pos": pos, "prs": prs, "neg": neg, "nrs": nrs}
@@ -129,9 +134,11 @@ def main():
                 for k, v in model.state_dict().items():
                     out[f"w{step + 1}/" + k] = v.detach().numpy().copy()
             out[f"loss{step}"] = np.float32(loss.item())
-        path = os.path.join(HERE, f"{kind}.npz")
+        path = os.path.join(HERE, f"{kind}.npz" if nh == 1 else f"{kind}_h{nh}.npz")
         np.savez_compressed(path, **out)
         print(kind, "->", path, os.path.getsize(path) // 1024, "KiB")
+    if cases:
+        return
 
     # get_Labels edge-case matrix (integer, bit-exact): ties, all-pad, all-fake, all-real
     edge = np.array([[0] * 10, [1] * 10, [2] * 10, [1, 2] * 5, [0, 0, 0, 0, 1, 1, 1, 2, 2, 2],
@@ -194,5 +201,7 @@ def c2_checksum():
 if __name__ == "__main__":
     if "--c2" in sys.argv:
         c2_checksum()
+    elif "--heads" in sys.argv:
+        main(HEAD_CASES)
     else:
         main()

@@ -11,17 +11,20 @@ KINDS = O.KINDS
 G_I, G_L, G_B = 1000, 20, 8
 
 
-def golden_cfg(kind, dropout=0.0):
+HEAD_CASES = (("SASRec", 2), ("SRFRN", 5), ("SRFU_B", 2))      # tests/golden/<kind>_h<heads>.npz (make_golden.py --heads)
+
+
+def golden_cfg(kind, dropout=0.0, heads=1):
     if kind == "SASRec":
-        return O.Cfg(kind, G_I, G_L, 50, dropout=dropout)
+        return O.Cfg(kind, G_I, G_L, 50, dropout=dropout, num_heads=heads)
     if kind in ("SRFR", "SRFRN"):
-        return O.Cfg(kind, G_I, G_L, 45, d_fake=5, dropout=dropout)
+        return O.Cfg(kind, G_I, G_L, 45, d_fake=5, dropout=dropout, num_heads=heads)
     nl = {"SRFU_B": 3, "SRFU_F": G_L + 1, "SRFU_R": 11}[kind]
-    return O.Cfg(kind, G_I, G_L, 50, n_labels=nl, dropout=dropout)
+    return O.Cfg(kind, G_I, G_L, 50, n_labels=nl, dropout=dropout, num_heads=heads)
 
 
-def load_golden(kind):
-    z = np.load(os.path.join(GOLDEN, f"{kind}.npz"))
+def load_golden(kind, heads=1):
+    z = np.load(os.path.join(GOLDEN, f"{kind}.npz" if heads == 1 else f"{kind}_h{heads}.npz"))
     g = {k: z[k] for k in z.files}
     sd = {k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("w/")}
     batch = tuple(torch.from_numpy(g[k]) for k in ("seq", "rsq", "pos", "prs", "neg", "nrs"))

@@ -318,12 +318,12 @@ def test_input_ring_slots_match_copy_in_steps():
 
 
 def test_unsupported_geometry_is_rejected():
-    """Two heads / hidden width > 64 are outside the fused kernels: the module must refuse on the device (no silent
-    fallback), both at the first forward and when a FusedTrainer is built on it."""
+    """Hidden width > 64 is outside the fused kernels: the module must refuse on the device (no silent fallback), both at the
+    first forward and when a FusedTrainer is built on it."""
     import srfrd_amd
     ids = torch.ones(2, 5, dtype=torch.int64, device="cuda")
-    for m in (srfrd_amd.SASRec(10, 5, 50, 0.0, 1, 2, "cuda").cuda(), srfrd_amd.SASRec(10, 5, 128, 0.0, 1, 1, "cuda").cuda()):
-        with pytest.raises(NotImplementedError, match="hidden width <= 64 and num_heads == 1"):
+    for m in (srfrd_amd.SASRec(10, 5, 128, 0.0, 1, 1, "cuda").cuda(), srfrd_amd.SASRec(10, 5, 96, 0.0, 1, 2, "cuda").cuda()):
+        with pytest.raises(NotImplementedError, match="hidden width <= 64"):
             m(None, ids, ids, ids, ids, ids, ids)
         with pytest.raises(NotImplementedError):
             m.flat_parameters()

@@ -4,15 +4,16 @@ import pytest
 import torch
 
 from oracle import srfrd_oracle as O
-from tests.helpers import GOLDEN, KINDS, drop_kbias, golden_cfg, load_golden, sub
+from tests.helpers import GOLDEN, HEAD_CASES, KINDS, drop_kbias, golden_cfg, load_golden, sub
 
 TOL = 2e-6
+CASES = [(k, 1) for k in KINDS] + list(HEAD_CASES)        # (class, num_heads)
 
 
-@pytest.mark.parametrize("kind", KINDS)
-def test_forward_matches_reference(kind):
-    g, sd, batch = load_golden(kind)
-    cfg = golden_cfg(kind)
+@pytest.mark.parametrize("kind,heads", CASES)
+def test_forward_matches_reference(kind, heads):
+    g, sd, batch = load_golden(kind, heads)
+    cfg = golden_cfg(kind, heads=heads)
     h, pl, nl = O.forward(cfg, sd, *batch)
     assert h.shape == g["hidden"].shape
     np.testing.assert_allclose(h.numpy(), g["hidden"], atol=TOL, rtol=0)
@@ -20,10 +21,10 @@ def test_forward_matches_reference(kind):
     np.testing.assert_allclose(nl.numpy(), g["neg_logits"], atol=TOL, rtol=0)
 
 
-@pytest.mark.parametrize("kind", KINDS)
-def test_predict_matches_reference(kind):
-    g, sd, batch = load_golden(kind)
-    cfg = golden_cfg(kind)
+@pytest.mark.parametrize("kind,heads", CASES)
+def test_predict_matches_reference(kind, heads):
+    g, sd, batch = load_golden(kind, heads)
+    cfg = golden_cfg(kind, heads=heads)
     out = O.predict(cfg, sd, batch[0], batch[1], torch.from_numpy(g["cands"]))
     np.testing.assert_allclose(out.numpy(), g["pred_logits"], atol=TOL, rtol=0)
     # top-10 indices bit-exact against the reference's logits
@@ -32,10 +33,10 @@ def test_predict_matches_reference(kind):
     assert (ref_top == my_top).all()
 
 
-@pytest.mark.parametrize("kind", KINDS)
-def test_train_step_matches_reference(kind):
-    g, sd, batch = load_golden(kind)
-    cfg = golden_cfg(kind)
+@pytest.mark.parametrize("kind,heads", CASES)
+def test_train_step_matches_reference(kind, heads):
+    g, sd, batch = load_golden(kind, heads)
+    cfg = golden_cfg(kind, heads=heads)
     loss, grads, *_ = O.grads_of(cfg, sd, batch)
     assert abs(float(loss) - float(g["loss0"])) < TOL
     gg = sub(g, "g/")
