@@ -15,6 +15,24 @@
 #include "../../include/srfrd_hip.h"
 #include "srfrd_rng.h"
 
+// Diagnostic build (tools/race_skew.py, -DSRFRD_SKEW=<wave mask>): every workgroup barrier is followed by a ~2 us sleep of
+// the waves whose bit is set in the mask.  Results must not change: a wave that reads a buffer early in a barrier interval
+// while another wave writes it late in the same interval (a missing barrier that normally "wins" by a wide margin) turns
+// into a test failure once the reader is the delayed one.
+#ifdef SRFRD_SKEW
+__device__ __forceinline__ void srfrd_skewed_barrier() {
+  __syncthreads();
+  // (wave-uniform test on a scalar register: a per-lane condition compiles to an EXEC mask around the sleeps, which
+  // execute - they are scalar instructions - whatever the mask holds: every wave would sleep)
+  const int w_ = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) & 15;
+  if ((SRFRD_SKEW >> w_) & 1) {
+    __builtin_amdgcn_s_sleep(40);
+    __builtin_amdgcn_s_sleep(40);
+  }
+}
+#define __syncthreads() srfrd_skewed_barrier()
+#endif
+
 // Two builds of the same sources: the default keeps a sequence's working set in LDS; with SRFRD_BUF_GLOBAL the same
 // kernels address a per-workgroup scratch in global memory instead (sequences too long for the 160 KiB LDS: slower,
 // but every shape runs on the GPU).  The variants live in different namespaces so both link into one library.
