@@ -167,8 +167,12 @@ static int encoder_fwd_impl(const srfrd_layout* lay, const void* item_table, con
     return launch_enc(encoder_fwd_kernel<50, 64, 8, 50>, grid, threads, lds, stream, a);
   }
   if (spec && threads == 512 && L == 100 && lay->kind == SRFRD_SASREC && getenv("SRFRD_NO_LSPEC") == nullptr) {
-    // BASELINE configs[3] geometry (seq_len 100): still LDS-resident in the forward, one workgroup per CU
+    // BASELINE configs[3] geometry (seq_len 100): still LDS-resident in the forward, one workgroup per CU.  The training
+    // instantiation runs 16 waves (7 x 4 tiles per weight GEMM: two rounds instead of three and a half; 0.468 -> 0.462 ms
+    // per C4 step - the 128-register budget of a 1024-thread workgroup takes back most of what the extra waves give)
     const bool train = pos_ids && neg_ids && save_x && loss_part && dropout_p > 0.0 && !dbg;
+    if (train && getenv("SRFRD_FWD_THREADS") == nullptr)
+      return launch_enc(encoder_fwd_kernel<50, 112, 16, 100, SRFRD_SASREC, 1, 50>, grid, 1024, lds, stream, a);
     return train ? launch_enc(encoder_fwd_kernel<50, 112, 8, 100, SRFRD_SASREC, 1, 50>, grid, threads, lds, stream, a)
                  : launch_enc(encoder_fwd_kernel<50, 112, 8, 100, SRFRD_SASREC, 0, 50>, grid, threads, lds, stream, a);
   }

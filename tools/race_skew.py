@@ -45,7 +45,8 @@ def build():
 
 def run(extra):
     rc = 0
-    for m in MASKS:
+    masks = os.environ.get("SRFRD_SKEW_MASKS", ",".join(MASKS)).split(",")      # (a subset: SRFRD_SKEW_MASKS=0x0001,0xfffe)
+    for m in masks:
         lib = os.path.join(OUT, f"libsrfrd_hip_{m}.so")
         if not os.path.exists(lib):
             raise SystemExit(f"{lib} is missing: run `python tools/race_skew.py build` first")
