@@ -6,7 +6,8 @@ namespace srfrd {
 
 // grad_dense[i] = sum_w slabs[w][i]: a block owns 64 columns; its 4 waves each sum an interleaved quarter of the
 // slabs (4 loads in flight per lane), then the 4 partials are added in wave order - a fixed summation tree, so the
-// result is bitwise reproducible.  Block 0 also reduces the BCE partials.
+// result is bitwise reproducible.  Block 0 also reduces the BCE partials.  (A float4 form - 16 columns x 16 slab groups per
+// block, a quarter of the load instructions - measured the same 10 us by events: the kernel waits on L2 / MALL, not on issue.)
 __global__ void __launch_bounds__(256) reduce_dense_kernel(const float* __restrict__ slabs, int n_slabs, int64_t n_dense,
                                                           float* __restrict__ grad_dense, const float* __restrict__ loss_part,
                                                           int B, float* __restrict__ stats, float* __restrict__ loss_out) {
@@ -341,8 +342,11 @@ extern "C" int srfrd_adam_pack_step(const srfrd_layout* lay, float* param, float
   d.blk_stride = blk_stride_of(lay->D);
   d.off_lc_w = (int)lay->off_lc_w; d.off_lc_b = (int)lay->off_lc_b; d.off_ll_w = (int)lay->off_ll_w; d.off_ll_b = (int)lay->off_ll_b;
   d.n_dense = (int)lay->n_dense;
+  // 768 = three 512-thread workgroups on each of the MI355X's 256 CUs, all resident at once, every CU with the same share
+  // (measured at C2, kernel time: 256 / 384 / 512 / 640 / 768 / 896 / 1024 / 1536 / 2048 workgroups -> 21.1 / 20.7 / 21.4 /
+  // 22.2 / 19.3 / 21.1 / 22.0 / 26.3 / 25.8 us; 1 M-item table 1.440 -> 1.431 ms per step)
   int64_t grid = ((n >> 2) + 1 + 511) / 512;
-  if (grid > 1024) grid = 1024;
+  if (grid > 768) grid = 768;
   hipLaunchKernelGGL(adam_pack_kernel, dim3((int)grid), dim3(512), 0, (hipStream_t)stream, param, grad, m, v, n, n_table_pad,
                      n_zero, (float)beta1, (float)beta2, (float)eps, state, stats, d, packed, lr, beta1, beta2, table_bf16,
                      table_bf16 ? lay->n_table : 0);
