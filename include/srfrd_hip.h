@@ -99,8 +99,9 @@ int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64_t* fwd_flo
  * dropped entry is stored negated); sequence-major (all blocks of one sequence are contiguous). */
 int64_t srfrd_aux_floats(const srfrd_layout* lay, int B, int L);
 
-/* [host] number of persistent workgroups the backward launches for batch B (= rows of `grad_slabs`). */
-int srfrd_bwd_grid(int B);
+/* [host] number of persistent workgroups the backward launches for batch B at sequence length L (= rows of `grad_slabs`):
+ * a function of the layout and the shape only. */
+int srfrd_bwd_grid(const srfrd_layout* lay, int B, int L);
 
 /* [host] floats per debug-tap slot and number of slots (tests only). */
 int srfrd_debug_shape(const srfrd_layout* lay, int L, int64_t* slot_floats, int32_t* n_slots);
@@ -169,7 +170,7 @@ int srfrd_encoder_fwd_last(const srfrd_layout* lay, const void* item_table, cons
  *  table_contrib: NULL, or (3, B, L, d_item) floats for the DETERMINISTIC item-table scatter: instead of the atomics every
  *    (target kind {pos, neg, input}, sequence, position) writes its row contribution here (zeros where it has none) and
  *    srfrd_table_reduce sums the rows of each item in a fixed order into grad_table (bitwise reproducible)
- *  grad_slabs (srfrd_bwd_grid(B), n_dense): per-workgroup partial dense gradients (fully overwritten)
+ *  grad_slabs (srfrd_bwd_grid(lay, B, L), n_dense): per-workgroup partial dense gradients (fully overwritten)
  */
 int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
                       const int64_t* input_ids, const int64_t* fake_ids,

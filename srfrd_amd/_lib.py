@@ -39,7 +39,7 @@ SIGNATURES = {
     "srfrd_layout_init": (_i, [_LP, _i, _i, _i, _i, _i, _i, _i, _i]),
     "srfrd_lds_bytes": (_i, [_LP, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "srfrd_scratch_floats": (_i, [_LP, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
-    "srfrd_bwd_grid": (_i, [_i]),
+    "srfrd_bwd_grid": (_i, [_LP, _i, _i]),
     "srfrd_debug_shape": (_i, [_LP, _i, C.POINTER(_i64), C.POINTER(C.c_int32)]),
     "srfrd_packed_floats": (_i64, [_LP]),
     "srfrd_pack_weights": (_i, [_LP, _P, _P, _P, _d, _d, _d, _P]),

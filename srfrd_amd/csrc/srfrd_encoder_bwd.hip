@@ -16,10 +16,25 @@ extern "C" int srfrd_long_launch_bwd(const void* args, int grid, int threads, in
 extern "C" int srfrd_bwd_slots_launch(const void* args, int grid, int L, int kind_variant, void* stream);    // srfrd_encoder_bwd_slots.hip
 extern "C" int srfrd_bwd_chunks_launch(const void* args, int grid, int kind_variant, void* stream);          // srfrd_encoder_bwd_chunks.hip
 
-extern "C" int srfrd_bwd_grid(int B) {
-  if (B <= 0) return SRFRD_E_ARG;
-  const int cu = num_cu();
-  return B < cu ? B : cu;
+// kind_variant of the slot-placed / row-chunked kernels (0 SASRec 50 + 0, 1 SRFR 45 + 5, 2 SRFRN 45 + 5, 3 SRFU_* 50 + 0), or -1
+static int slots_variant(const srfrd_layout* lay) {
+  if (lay->D != 50 || lay->n_heads != 1) return -1;
+  if (lay->kind == SRFRD_SASREC) return 0;
+  if (lay->kind == SRFRD_SRFR && lay->d_item == 45) return 1;
+  if (lay->kind == SRFRD_SRFRN && lay->d_item == 45) return 2;
+  if (lay->kind >= SRFRD_SRFU_B && lay->d_item == 50) return 3;
+  return -1;
+}
+
+// The reference's default geometry (seq_len 50, hidden 50: BASELINE configs[1] / [2]) runs the slot-placed backward with its
+// six [52][54] slots = 76 KB of LDS: TWO workgroups per CU, where the first-generation kernel's ten matrices (150 KB) allow
+// one.  A function of the shape only (never of the environment switches below: callers size `grad_slabs` with it).
+static bool two_per_cu(const srfrd_layout* lay, int L) { return L == 50 && slots_variant(lay) >= 0; }
+
+extern "C" int srfrd_bwd_grid(const srfrd_layout* lay, int B, int L) {
+  if (!lay || B <= 0 || L <= 0) return SRFRD_E_ARG;
+  const int wgs = num_cu() * (two_per_cu(lay, L) ? 2 : 1);
+  return B < wgs ? B : wgs;
 }
 
 extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
@@ -44,21 +59,24 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table
   srfrd_debug_shape(lay, L, &a.dbg_slot, nullptr);
   const Geom g = make_geom(L, lay->D);
   const int64_t lds = bwd_lds_floats(g, lay->n_blocks) * 4;
-  const int grid = srfrd_bwd_grid(B);
+  const int grid = srfrd_bwd_grid(lay, B, L);
 #ifdef SRFRD_STAMPS
   const bool taps = false;                     // (diagnostic build: `dbg` receives the phase stamps)
 #else
   const bool taps = dbg != nullptr;
 #endif
+  if (two_per_cu(lay, L) && !taps && getenv("SRFRD_NO_SLOTS50") == nullptr && getenv("SRFRD_GENERIC") == nullptr &&
+      getenv("SRFRD_NO_LSPEC") == nullptr) {
+    // seq_len 50 (fused training step or autograd backward): the slot-placed kernel, two workgroups per CU.  (The switches
+    // select the first-generation kernel on the same grid - one sequence per workgroup, half of them resident at a time.)
+    rc = srfrd_bwd_slots_launch(&a, grid, L, slots_variant(lay), stream);
+    if (rc != SRFRD_E_UNSUPPORTED) return rc;
+  }
   if (lds > kLdsLimit && !taps && lay->D == 50 && lay->n_heads == 1 &&
       getenv("SRFRD_NO_SLOTS") == nullptr && getenv("SRFRD_GENERIC") == nullptr) {
     // a long sequence (fused training step or autograd backward): the slot-placed, query-chunked LDS-resident kernel where
     // one is built, the row-chunked one otherwise
-    int kv = -1;
-    if (lay->kind == SRFRD_SASREC) kv = 0;
-    else if (lay->kind == SRFRD_SRFR && lay->d_item == 45) kv = 1;
-    else if (lay->kind == SRFRD_SRFRN && lay->d_item == 45) kv = 2;
-    else if (lay->kind >= SRFRD_SRFU_B && lay->d_item == 50) kv = 3;
+    const int kv = slots_variant(lay);
     if (kv >= 0) {
       rc = getenv("SRFRD_NO_SLOT_KERNEL") ? SRFRD_E_UNSUPPORTED : srfrd_bwd_slots_launch(&a, grid, L, kv, stream);
       if (rc != SRFRD_E_UNSUPPORTED) return rc;

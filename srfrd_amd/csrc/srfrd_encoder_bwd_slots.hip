@@ -28,6 +28,14 @@ extern "C" int srfrd_bwd_slots_launch(const void* args, int grid, int L, int kin
       case 3: return SRFRD_SL(100, -1, 50);
     }
   }
+  if (L == 50) {
+    switch (kind_variant) {
+      case 0: return SRFRD_SL(50, SRFRD_SASREC, 50);
+      case 1: return SRFRD_SL(50, SRFRD_SRFR, 45);
+      case 2: return SRFRD_SL(50, SRFRD_SRFRN, 45);
+      case 3: return SRFRD_SL(50, -1, 50);
+    }
+  }
 #undef SRFRD_SL
   return SRFRD_E_UNSUPPORTED;
 }

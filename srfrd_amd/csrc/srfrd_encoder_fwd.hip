@@ -65,7 +65,7 @@ extern "C" int srfrd_scratch_floats(const srfrd_layout* lay, int B, int L, int64
   int gf = num_cu();
   if (gf > B) gf = B;
   if (fwd_floats) *fwd_floats = f * 4 <= kLdsLimit ? 0 : ((f + 2 * kSlack + 63) & ~63ll) * gf;
-  if (bwd_floats) *bwd_floats = bw * 4 <= kLdsLimit ? 0 : ((bw + 2 * kSlack + 63) & ~63ll) * srfrd_bwd_grid(B);
+  if (bwd_floats) *bwd_floats = bw * 4 <= kLdsLimit ? 0 : ((bw + 2 * kSlack + 63) & ~63ll) * srfrd_bwd_grid(lay, B, L);
   return 0;
 }
 

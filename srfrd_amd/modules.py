@@ -281,7 +281,7 @@ class _SRFRDBase(nn.Module):
         B, L = inp.shape
         dev = inp.device
         gflat = torch.zeros(self.n_flat, device=dev, dtype=torch.float32)
-        n_slabs = _lib.lib().srfrd_bwd_grid(B)
+        n_slabs = _lib.lib().srfrd_bwd_grid(C.byref(lay), B, L)
         slabs = torch.empty(n_slabs, lay.n_dense, device=dev, dtype=torch.float32)
         scratch, n_scr = self._scratch_for(B, L, backward=True)
         lay_t, tab = self._table_args()

@@ -87,7 +87,7 @@ class FusedTrainer:
         self.deterministic = bool(deterministic)
         self.contrib = torch.zeros(3, B, L, lay.d_item, **f32) if self.deterministic else None
         self.keys = torch.zeros(3, B, L, device=dev, dtype=torch.int64) if self.deterministic else None
-        self.n_slabs = _lib.lib().srfrd_bwd_grid(B)
+        self.n_slabs = _lib.lib().srfrd_bwd_grid(C.byref(lay), B, L)
         self.slabs = torch.empty(self.n_slabs, lay.n_dense, **f32)
         # Input ring: `slots` resident (6, B, L) id buffers.  A producer (DeviceSampler, a loader thread's H2D copy)
         # fills slot k + 1 while step k runs and calls step_slot(k + 1): no staging copy on the step's stream.  Slot 0

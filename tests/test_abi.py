@@ -51,7 +51,7 @@ def test_lds_capability_query():
     assert _lib.scratch_floats(lay, 512, 50) == (0, 0)             # LDS-resident
     f200, b200 = _lib.scratch_floats(lay, 512, 200)                 # long-sequence build: global scratch per workgroup
     assert f200 > 0 and b200 > 0 and _lib.scratch_floats(lay, 512, 100)[1] > 0
-    assert _lib.lib().srfrd_bwd_grid(7) == 7
+    assert _lib.lib().srfrd_bwd_grid(C.byref(lay), 7, 50) == 7
     assert _lib.lib().srfrd_packed_floats(C.byref(lay)) == (2 * 6 + 1) * 2 * 4096
 
 
