@@ -98,9 +98,9 @@ def pmc_traffic(kernel_c_name):
             continue
     if ks is None:
         return None
-    stem = kernel_c_name.replace("srfrd_", "") + "_kernel"          # srfrd_encoder_bwd -> encoder_bwd_kernel
+    stem = kernel_c_name.replace("srfrd_", "")                      # srfrd_encoder_bwd -> encoder_bwd[_slots]_kernel<...>
     for name, d in ks.items():
-        if name.startswith(stem) and "hbm_bytes_per_launch" in d and "<0, 0, 0>" not in name:
+        if name.startswith(stem) and "_kernel" in name and "hbm_bytes_per_launch" in d and "<0, 0, 0>" not in name:
             return d["hbm_bytes_per_launch"]["total"]
     return None
 

@@ -174,5 +174,7 @@ if __name__ == "__main__":
         run()
     if "--c4" in sys.argv:
         run_c4()
+    if "--c2s" in sys.argv:       # seq_len 50 (BASELINE configs[1]) on the slot-placed backward, two workgroups per CU
+        run_c4(50_000, 50, "bwd_slots")
     if "--c5" in sys.argv:
         run_c4(1_000_000, 200, "bwd_chunks")
