@@ -229,11 +229,16 @@ def test_bench_geometry_autograd_matches_oracle(kind):
         assert maxerr(p.grad, grads_o[k]) < TOL, k
 
 
+@pytest.mark.parametrize("first_gen", [False, True])
 @pytest.mark.parametrize("kind", ["SASRec", "SRFR", "SRFRN", "SRFU_B"])
-def test_bench_geometry_fused_step_with_dropout_matches_oracle(kind):
+def test_bench_geometry_fused_step_with_dropout_matches_oracle(kind, first_gen, monkeypatch):
     """The train-mode instantiations (fused BCE, dropout 0.5, checkpoints, loss sums): two FusedTrainer steps at
-    seq_len 50 / hidden 50 vs the oracle's step with the same coordinate-hash masks (step seeds from the same base)."""
+    seq_len 50 / hidden 50 vs the oracle's step with the same coordinate-hash masks (step seeds from the same base).
+    The backward is the slot-placed kernel (two workgroups per CU); first_gen: SRFRD_NO_SLOTS50 selects the first-generation
+    backward on the same grid and slabs."""
     import srfrd_amd
+    if first_gen:
+        monkeypatch.setenv("SRFRD_NO_SLOTS50", "1")
     from tests.gpu_util import build_model, cuda, maxerr, random_sd
     from tests.helpers import drop_kbias
     cfg = _cfg50(kind, dropout=0.5)
@@ -255,14 +260,18 @@ def test_bench_geometry_fused_step_with_dropout_matches_oracle(kind):
     assert frac > 0.3, frac       # (share of elements held to 1e-4 or tighter)
 
 
+@pytest.mark.parametrize("first_gen", [False, True])
 @pytest.mark.parametrize("kind", ["SASRec", "SRFRN"])
-def test_more_sequences_than_workgroups_accumulate_in_the_slabs(kind):
-    """B = 600 > 2 x 256 CUs: persistent backward workgroups process up to three sequences each, so the dense
-    gradients go through the slab read-modify-write (old tile values as the MFMA accumulators' initial value) twice.
+def test_more_sequences_than_workgroups_accumulate_in_the_slabs(kind, first_gen, monkeypatch):
+    """B = 1100 > 2 x (2 x 256 CUs): persistent backward workgroups process up to three sequences each, so the dense
+    gradients go through the slab read-modify-write (old tile values as the MFMA accumulators' initial value) twice - in
+    the slot-placed kernel's read-modify-write instantiation, and (first_gen) in the first-generation kernel.
     Gradients (autograd path) and one fused dropout step vs the oracle."""
     import srfrd_amd
+    if first_gen:
+        monkeypatch.setenv("SRFRD_NO_SLOTS50", "1")
     from tests.gpu_util import build_model, cuda, maxerr, random_sd
-    B = 600
+    B = 1100
     cfg = _cfg50(kind)
     sd = random_sd(cfg, 11)
     model = build_model(cfg, sd).train()
