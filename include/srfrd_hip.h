@@ -245,6 +245,18 @@ int srfrd_adam_pack_step(const srfrd_layout* lay, float* param, float* grad, flo
 int srfrd_table_to_bf16(const float* src, int64_t n, uint16_t* out, void* stream);
 
 /* loss = stats[0]/stats[2] + stats[1]/stats[2] -> loss_out[0] (reference trainer.py:36-38). */
+/* The `l2_emb * ||p||_2` terms of reference trainer.py:39 (one Frobenius norm per parameter tensor) for the fused step.
+ * srfrd_l2_norms: the n_seg parameter tensors are [seg_off[k], seg_off[k] + seg_len[k]) of `param` (device int64 arrays;
+ *   segment 0 = the item table, the others lie at or above n_table_pad); partial: 240 + n_seg floats of workspace;
+ *   l2buf[0] = l2_emb / ||table||, l2buf[1] = l2_emb * sum_k ||p_k|| (add it to the loss); dense_scale (n_dense floats,
+ *   zero-initialised by the caller once): l2_emb / ||p|| of the tensor each dense element belongs to.
+ * srfrd_l2_apply: grad[i] += stats[2] * (l2_emb / ||p||) * param[i] over [i0, i1) (stats[2] = the count the Adam step
+ *   divides by; NULL: 1) - enqueue between the gradient exchange and the Adam step of that range. */
+int srfrd_l2_norms(const float* param, const int64_t* seg_off, const int64_t* seg_len, int n_seg, int64_t n_table_pad,
+                   double l2_emb, float* partial, float* l2buf, float* dense_scale, void* stream);
+int srfrd_l2_apply(float* grad, const float* param, int64_t i0, int64_t i1, int64_t n_table_pad, const float* l2buf,
+                   const float* dense_scale, const float* stats, void* stream);
+
 int srfrd_loss_finalize(const float* stats, float* loss_out, void* stream);
 
 /* get_Labels (reference SRFR_model.py:546-570) and SRFRN.predict's user label (:244); labels int64 (B).

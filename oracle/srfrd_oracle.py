@@ -338,8 +338,10 @@ class Adam:
                 p.addcdiv_(self.m[k], denom, value=-self.lr / bc1)
 
 
-def grads_of(cfg: Cfg, sd, batch, train=False, seed=0, b0=0):
-    """batch = (seq, rsq, pos, prs, neg, nrs) int64 (B,L).  -> (loss, {name: grad}, hidden, pl, nl)."""
+def grads_of(cfg: Cfg, sd, batch, train=False, seed=0, b0=0, l2_emb=0.0):
+    """batch = (seq, rsq, pos, prs, neg, nrs) int64 (B,L).  -> (loss, {name: grad}, hidden, pl, nl).
+    l2_emb: reference trainer.py:39 - ``loss += l2_emb * torch.norm(p)`` for EVERY parameter tensor (its gradient
+    l2_emb * p / ||p|| reaches the padding rows too: it does not pass through the embedding lookup)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
     seq, rsq, pos, prs, neg, nrs = batch
     h, pl, nl = forward(cfg, leaves, seq, rsq, pos, prs, neg, nrs, train=train, seed=seed, b0=b0)
@@ -350,11 +352,18 @@ def grads_of(cfg: Cfg, sd, batch, train=False, seed=0, b0=0):
     grads[key_item(cfg)][0].zero_()
     if cfg.kind in ("SRFR", "SRFRN"):
         grads[key_side(cfg)][0].zero_()
-    return loss.detach(), grads, h.detach(), pl.detach(), nl.detach()
+    loss = loss.detach()
+    if l2_emb != 0.0:
+        for k, v in sd.items():
+            nrm = torch.norm(v.detach())
+            loss = loss + l2_emb * nrm
+            if float(nrm) > 0.0:
+                grads[k] = grads[k] + l2_emb * v.detach() / nrm
+    return loss, grads, h.detach(), pl.detach(), nl.detach()
 
 
-def train_step(cfg: Cfg, sd, opt: Adam, batch, train=True, seed=0, b0=0):
-    loss, grads, *_ = grads_of(cfg, sd, batch, train=train, seed=seed, b0=b0)
+def train_step(cfg: Cfg, sd, opt: Adam, batch, train=True, seed=0, b0=0, l2_emb=0.0):
+    loss, grads, *_ = grads_of(cfg, sd, batch, train=train, seed=seed, b0=b0, l2_emb=l2_emb)
     opt.step(sd, grads)
     return loss
 

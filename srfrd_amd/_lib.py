@@ -57,6 +57,8 @@ SIGNATURES = {
     "srfrd_adam_pack_step": (_i, [_LP, _P, _P, _P, _P, _i64, _i64, _i64, _d, _d, _d, _d, _P, _P, _P, _P, _P]),
     "srfrd_table_to_bf16": (_i, [_P, _i64, _P, _P]),
     "srfrd_loss_finalize": (_i, [_P, _P, _P]),
+    "srfrd_l2_norms": (_i, [_P, _P, _P, _i, _i64, _d, _P, _P, _P, _P]),
+    "srfrd_l2_apply": (_i, [_P, _P, _i64, _i64, _i64, _P, _P, _P, _P]),
     "srfrd_user_labels": (_i, [_i, _P, _i, _i, _P, _P]),
     "srfrd_check_ids": (_i, [_P, _P, _P, _P, _P, _P, _i64, _i64, _i64, _P, _P]),
     "srfrd_predict_logits": (_i, [_LP, _P, _P, _P, _i, _i, _P, _i, _i64, _P, _P, _P]),

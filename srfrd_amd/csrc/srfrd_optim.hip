@@ -268,6 +268,80 @@ __global__ void __launch_bounds__(512) adam_pack_kernel(float* __restrict__ para
   }
 }
 
+// ---- l2_emb * sum_p ||p||_2 of reference trainer.py:39 (one Frobenius norm per parameter tensor), for the fused step.
+// Pass A: workgroup g < n_tw sums the squares of its contiguous share of segment 0 (the item table), workgroup n_tw + k - 1
+// those of dense segment k: fixed shares, fixed in-block tree.  Pass B (one workgroup): norms in segment order,
+// l2buf = {l2 / ||table||, l2 * sum of norms}, and dense_scale[j] = l2 / ||p|| of the tensor dense element j belongs to
+// (0 in the alignment gaps and for an all-zero tensor, where torch's norm backward is 0 as well).
+__global__ void __launch_bounds__(256) l2_partial_kernel(const float* __restrict__ param, const int64_t* __restrict__ seg_off,
+                                                        const int64_t* __restrict__ seg_len, int n_tw, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int g = blockIdx.x;
+  int64_t lo, hi;
+  if (g < n_tw) {
+    const int64_t n = seg_len[0], per = ((n + n_tw - 1) / n_tw + 3) & ~3ll;
+    lo = seg_off[0] + g * per;
+    hi = seg_off[0] + (g + 1) * per < seg_off[0] + n ? seg_off[0] + (g + 1) * per : seg_off[0] + n;
+  } else {
+    const int k = g - n_tw + 1;
+    lo = seg_off[k];
+    hi = lo + seg_len[k];
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t i = lo + threadIdx.x;
+  for (; i + 768 < hi; i += 1024) {
+    const float a = param[i], b = param[i + 256], c = param[i + 512], d = param[i + 768];
+    s0 += a * a; s1 += b * b; s2 += c * c; s3 += d * d;
+  }
+  for (; i < hi; i += 256) { const float a = param[i]; s0 += a * a; }
+  float s = wave_sum((s0 + s1) + (s2 + s3));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[g] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256) l2_finish_kernel(const float* __restrict__ partial, const int64_t* __restrict__ seg_off,
+                                                       const int64_t* __restrict__ seg_len, int n_seg, int n_tw,
+                                                       int64_t n_table_pad, float l2, float* __restrict__ l2buf,
+                                                       float* __restrict__ dense_scale) {
+  __shared__ float s_scale[128];
+  __shared__ float s_tab[4];
+  float t = 0.f;
+  for (int g = threadIdx.x; g < n_tw; g += 256) t += partial[g];       // (a thread owns fixed entries: a fixed tree)
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) s_tab[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float total = 0.f;
+    for (int k = 0; k < n_seg; ++k) {
+      const float sq = k == 0 ? (s_tab[0] + s_tab[1]) + (s_tab[2] + s_tab[3]) : partial[n_tw + k - 1];
+      const float nrm = sqrtf(sq);
+      total += nrm;
+      s_scale[k] = nrm > 0.f ? l2 / nrm : 0.f;
+    }
+    l2buf[0] = s_scale[0];
+    l2buf[1] = l2 * total;
+  }
+  __syncthreads();
+  for (int k = 1; k < n_seg; ++k) {
+    const int64_t base = seg_off[k] - n_table_pad;
+    const float sc = s_scale[k];
+    for (int64_t j = threadIdx.x; j < seg_len[k]; j += 256) dense_scale[base + j] = sc;
+  }
+}
+
+// grad[i] += count * (l2 / ||p||) * p[i] over [i0, i1): ahead of an Adam step that divides by the (global) count of targets
+__global__ void __launch_bounds__(256) l2_apply_kernel(float* __restrict__ grad, const float* __restrict__ param, int64_t i0,
+                                                      int64_t i1, int64_t n_table_pad, const float* __restrict__ l2buf,
+                                                      const float* __restrict__ dense_scale, const float* __restrict__ stats) {
+  const float cnt = stats ? stats[2] : 1.0f, ts = l2buf[0] * cnt;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = i0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += stride) {
+    const float sc = i < n_table_pad ? ts : dense_scale[i - n_table_pad] * cnt;
+    grad[i] += sc * param[i];
+  }
+}
+
 __global__ void loss_finalize_kernel(const float* stats, float* loss_out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) loss_out[0] = stats[0] / stats[2] + stats[1] / stats[2];
 }
@@ -350,6 +424,29 @@ extern "C" int srfrd_adam_pack_step(const srfrd_layout* lay, float* param, float
   hipLaunchKernelGGL(adam_pack_kernel, dim3((int)grid), dim3(512), 0, (hipStream_t)stream, param, grad, m, v, n, n_table_pad,
                      n_zero, (float)beta1, (float)beta2, (float)eps, state, stats, d, packed, lr, beta1, beta2, table_bf16,
                      table_bf16 ? lay->n_table : 0);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_l2_norms(const float* param, const int64_t* seg_off, const int64_t* seg_len, int n_seg, int64_t n_table_pad,
+                              double l2_emb, float* partial, float* l2buf, float* dense_scale, void* stream) {
+  if (!param || !seg_off || !seg_len || !partial || !l2buf || !dense_scale || n_seg < 1 || n_seg > 128 || n_table_pad < 0)
+    return SRFRD_E_ARG;
+  const int n_tw = 240;
+  hipLaunchKernelGGL(l2_partial_kernel, dim3(n_tw + n_seg - 1), dim3(256), 0, (hipStream_t)stream, param, seg_off, seg_len, n_tw,
+                     partial);
+  hipLaunchKernelGGL(l2_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, seg_off, seg_len, n_seg, n_tw,
+                     n_table_pad, (float)l2_emb, l2buf, dense_scale);
+  return (int)hipGetLastError();
+}
+
+extern "C" int srfrd_l2_apply(float* grad, const float* param, int64_t i0, int64_t i1, int64_t n_table_pad, const float* l2buf,
+                              const float* dense_scale, const float* stats, void* stream) {
+  if (!grad || !param || !l2buf || !dense_scale || i0 < 0 || i1 < i0) return SRFRD_E_ARG;
+  if (i0 == i1) return 0;
+  int64_t grid = (i1 - i0 + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(l2_apply_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, grad, param, i0, i1, n_table_pad, l2buf,
+                     dense_scale, stats);
   return (int)hipGetLastError();
 }
 

@@ -5,8 +5,8 @@
 as five stream-ordered launches on persistent buffers (encoder_fwd, encoder_bwd, reduce_dense [+ loss], adam_step,
 pack_weights [+ optimizer-state advance for the next step]), captured into one HIP graph when no collective sits in the middle.  Differences from the reference
 loop, all behaviour-preserving: the loss is never synchronised to the host (``loss`` stays a device scalar), the
-``l2_emb * ||theta||`` term (trainer.py:39) is supported only at its default 0.0 where it contributes exactly nothing,
-and dropout masks come from the coordinate hash of csrc/srfrd_rng.h instead of torch's Bernoulli stream.
+``l2_emb * ||p||`` terms (trainer.py:39: one Frobenius norm per parameter tensor) cost two small launches and one pass over
+the gradient when l2_emb != 0 and nothing at the reference's 0.0, and dropout masks come from the coordinate hash of csrc/srfrd_rng.h instead of torch's Bernoulli stream.
 
 Data parallel (no reference counterpart): one process per GPU, the global batch split by sequence,
 parameters replicated, dropout masks keyed by the GLOBAL sequence index.  srfrd_amd/exchange.py holds the two forms of
@@ -45,9 +45,6 @@ class FusedTrainer:
         """``deterministic``: the item-table gradient is scattered by a stable sort + per-item ordered sums instead of float
         atomics - every step bitwise reproducible (the dense gradients already are: fixed slab tree), at the cost of one
         sort of 3 B L keys per step."""
-        if l2_emb != 0.0:
-            raise NotImplementedError("fused step supports l2_emb == 0.0 (the reference default, trainer.py:124); use the "
-                                      "autograd path (model(...) + torch.optim) for a non-zero L2 term")
         self.model = model
         model._ensure_flat()
         self.lay = model.layout
@@ -82,6 +79,16 @@ class FusedTrainer:
             self.stats = self.grad[self.n_flat:]
             self.m = torch.zeros(self.n_flat, **f32)
             self.v = torch.zeros(self.n_flat, **f32)
+        # l2_emb * sum_p ||p|| (trainer.py:39): one segment per parameter tensor of the flat vector (the item table first)
+        self.l2 = float(l2_emb)
+        if self.l2 != 0.0:
+            segs = [(off, p.numel()) for p, off in model._slots]
+            assert segs[0][0] == 0 and all(off >= self.n_tab for off, _ in segs[1:])
+            self.seg_off = torch.tensor([o for o, _ in segs], device=dev, dtype=torch.int64)
+            self.seg_len = torch.tensor([n for _, n in segs], device=dev, dtype=torch.int64)
+            self.l2_partial = torch.zeros(240 + len(segs), **f32)
+            self.l2buf = torch.zeros(4, **f32)
+            self.l2_dense = torch.zeros(self.n_flat - self.n_tab, **f32)
         self.state = torch.zeros(32, device=dev, dtype=torch.int32)
         self.state[1] = int(seed) & 0x7FFFFFFF
         self.deterministic = bool(deterministic)
@@ -126,8 +133,16 @@ class FusedTrainer:
         p = self.model.dropout_rate if self.model.training else 0.0
         return ids, fk, pfk, nfk, p, C.c_void_p(self.state.data_ptr() + 8), self.rank * self.B
 
+    def _enqueue_l2_apply(self, grad_ptr, param, i0, i1):
+        """grad[i0:i1] += count * l2_emb * p / ||p|| (the Adam step that follows divides by the count)"""
+        check(_lib.lib().srfrd_l2_apply(grad_ptr, ptr(param), i0, min(i1, self.n_flat), self.n_tab, ptr(self.l2buf),
+                                        ptr(self.l2_dense), ptr(self.stats), self._stream()), "srfrd_l2_apply")
+
     def _enqueue_fwd(self, slot: int = 0):
         L_, lay, st = _lib.lib(), self.lay, self._stream()
+        if self.l2 != 0.0:               # norms of the parameters this step's forward uses
+            check(L_.srfrd_l2_norms(ptr(self.flat), ptr(self.seg_off), ptr(self.seg_len), self.seg_off.numel(), self.n_tab,
+                                    self.l2, ptr(self.l2_partial), ptr(self.l2buf), ptr(self.l2_dense), st), "srfrd_l2_norms")
         ids, fk, pfk, nfk, p, seed_dev, seq0 = self._ids_of(slot)
         lay_t, tab = self.model._table_args()
         check(L_.srfrd_encoder_fwd(C.byref(lay_t), tab, self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
@@ -167,12 +182,16 @@ class FusedTrainer:
     def _enqueue_update(self):
         """single rank / all-reduce form: Adam over the whole flat vector + re-pack + optimizer-state advance, one launch"""
         L_, st = _lib.lib(), self._stream()
+        if self.l2 != 0.0:
+            self._enqueue_l2_apply(ptr(self.grad), self.flat, 0, self.n_flat)
         check(L_.srfrd_adam_pack_step(C.byref(self.lay), ptr(self.flat), ptr(self.grad), ptr(self.m), ptr(self.v),
                                       self.n_flat, self.n_tab, self.n_tab, self.lr, self.betas[0], self.betas[1], self.eps,
                                       ptr(self.state), ptr(self.stats), ptr(self.packed), ptr(self.model._table16), st),
               "srfrd_adam_pack_step")
         if self.world > 1:
             check(L_.srfrd_loss_finalize(ptr(self.stats), ptr(self.loss), st), "srfrd_loss_finalize")
+        if self.l2 != 0.0:
+            self.loss.add_(self.l2buf[1:2])
 
     def _enqueue_shard_update(self):
         """sharded form, between the reduce-scatter and the all-gather: re-zero the local item-table gradient (the atomics
@@ -181,6 +200,8 @@ class FusedTrainer:
         L_, st, ex = _lib.lib(), self._stream(), self.ex
         self.grad[:self.n_tab].zero_()
         bias = 4 * ex.i0
+        if self.l2 != 0.0:
+            self._enqueue_l2_apply(C.c_void_p(self.recv.data_ptr() - bias), self.flat_pad, ex.i0, ex.i1)
         check(L_.srfrd_adam_step(ptr(self.flat_pad), C.c_void_p(self.recv.data_ptr() - bias), C.c_void_p(self.m.data_ptr() - bias),
                                  C.c_void_p(self.v.data_ptr() - bias), ex.n_pad, ex.i0, ex.i1, 0, self.betas[0], self.betas[1],
                                  self.eps, ptr(self.state), ptr(self.stats), None, 0, st), "srfrd_adam_step")
@@ -193,6 +214,8 @@ class FusedTrainer:
         if self.model._table16 is not None:      # bf16 shadow of the all-gathered item table (every rank needs all rows)
             check(L_.srfrd_table_to_bf16(ptr(self.flat), self.lay.n_table, ptr(self.model._table16), st), "srfrd_table_to_bf16")
         check(L_.srfrd_loss_finalize(ptr(self.stats), ptr(self.loss), st), "srfrd_loss_finalize")
+        if self.l2 != 0.0:
+            self.loss.add_(self.l2buf[1:2])
 
     def _capture(self):
         # warm-up on a side stream (sets the LDS attributes, loads code objects), then capture

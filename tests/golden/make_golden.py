@@ -87,12 +87,15 @@ def t64(a):
 HEAD_CASES = (("SASRec", 2), ("SRFRN", 5), ("SRFU_B", 2))      # num_heads > 1: <kind>_h<heads>.npz (--heads)
 
 
-def main(cases=None):
+L2_CASES = (("SRFRN", 1),)      # l2_emb = 0.05 (reference trainer.py:39 with a non-zero config.l2_emb): <kind>_l2.npz (--l2)
+
+
+def main(cases=None, l2_emb=0.0):
     torch.set_num_threads(1)
     all_kinds = ["SASRec", "SRFR", "SRFRN", "SRFU_B", "SRFU_F", "SRFU_R"]
     for kind, nh in (cases or [(k, NH) for k in all_kinds]):
         k_i = all_kinds.index(kind)
-        torch.manual_seed(1234 + k_i + 100 * (nh - 1))
+        torch.manual_seed(1234 + k_i + 100 * (nh - 1) + (7 if l2_emb else 0))
         model = build(kind, 0.0, nh)
         trainer_init(model)
         seq, rsq, pos, prs, neg, nrs = make_inputs(7 + k_i)
@@ -123,7 +126,7 @@ def main(cases=None):
             idx = torch.where(t64(pos) != 0)
             loss = crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
             for p in model.parameters():
-                loss = loss + 0.0 * torch.norm(p)
+                loss = loss + l2_emb * torch.norm(p)
             loss.backward()
             if step == 0:
                 out["loss0"] = np.float32(loss.item())
@@ -134,7 +137,8 @@ def main(cases=None):
                 for k, v in model.state_dict().items():
                     out[f"w{step + 1}/" + k] = v.detach().numpy().copy()
             out[f"loss{step}"] = np.float32(loss.item())
-        path = os.path.join(HERE, f"{kind}.npz" if nh == 1 else f"{kind}_h{nh}.npz")
+        path = os.path.join(HERE, f"{kind}_l2.npz" if l2_emb else (f"{kind}.npz" if nh == 1 else f"{kind}_h{nh}.npz"))
+        out["l2_emb"] = np.float64(l2_emb)
         np.savez_compressed(path, **out)
         print(kind, "->", path, os.path.getsize(path) // 1024, "KiB")
     if cases:
@@ -203,5 +207,7 @@ if __name__ == "__main__":
         c2_checksum()
     elif "--heads" in sys.argv:
         main(HEAD_CASES)
+    elif "--l2" in sys.argv:
+        main(L2_CASES, l2_emb=0.05)
     else:
         main()

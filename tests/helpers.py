@@ -23,8 +23,8 @@ def golden_cfg(kind, dropout=0.0, heads=1):
     return O.Cfg(kind, G_I, G_L, 50, n_labels=nl, dropout=dropout, num_heads=heads)
 
 
-def load_golden(kind, heads=1):
-    z = np.load(os.path.join(GOLDEN, f"{kind}.npz" if heads == 1 else f"{kind}_h{heads}.npz"))
+def load_golden(kind, heads=1, l2=False):
+    z = np.load(os.path.join(GOLDEN, f"{kind}_l2.npz" if l2 else (f"{kind}.npz" if heads == 1 else f"{kind}_h{heads}.npz")))
     g = {k: z[k] for k in z.files}
     sd = {k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("w/")}
     batch = tuple(torch.from_numpy(g[k]) for k in ("seq", "rsq", "pos", "prs", "neg", "nrs"))

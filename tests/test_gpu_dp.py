@@ -49,6 +49,14 @@ def test_two_ranks_equal_one_rank(exchange, graph):
     assert rep["weights_held_to_1e-4_or_tighter"] > 0.3
 
 
+@pytest.mark.parametrize("exchange", ["sharded", "allreduce"])
+def test_two_ranks_l2_emb(exchange):
+    """l2_emb != 0: the norm terms are applied once, to each rank's slice (sharded) or to the all-reduced gradient"""
+    rep = run_dp_parity("--exchange", exchange, "--l2-emb", "0.05")
+    assert rep["world"] == 2 and rep["ok"]
+    assert rep["max_loss_diff"] < 1e-5 and rep["weight_violations"] == 0 and rep["replicas_bit_identical"]
+
+
 def test_three_ranks_srfrn_sharded():
     """uneven shard edges (n_flat is not a multiple of 3 x 4) and the [item || fake] kind"""
     rep = run_dp_parity("--exchange", "sharded", "--kind", "SRFRN", "--batch", "24", nproc=3)

@@ -431,3 +431,27 @@ def test_trainer_state_dict_resumes_bitwise_and_interoperates_with_torch_adam():
     for k in sdC:
         d = (sdC[k] - sdD[k]).abs().double().cpu()
         assert not bool((d > adam_tolerance([g[k].cpu()])).any()), k
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_trainer_l2_emb_matches_golden(graph):
+    """reference trainer.py:39 with config.l2_emb = 0.05 (tests/golden/SRFRN_l2.npz): the fused step's loss curve and the
+    weights after 1 and 3 steps - every parameter tensor, the item table's padding row included, carries the norm term."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, maxerr
+    g, sd, batch = load_golden("SRFRN", l2=True)
+    cfg = golden_cfg("SRFRN")
+    model = build_model(cfg, sd).train()
+    tr = srfrd_amd.FusedTrainer(model, 8, 20, lr=1e-3, betas=(0.9, 0.98), l2_emb=float(g["l2_emb"]), use_graph=graph)
+    seq, rsq, pos, prs, neg, nrs = cuda(*batch)
+    w1, w3 = sub(g, "w1/"), sub(g, "w3/")
+    for step in range(3):
+        loss = tr.step(None, seq, rsq, pos, prs, neg, nrs)
+        assert abs(float(loss.cpu()) - float(g[f"loss{step}"])) < TOL, step
+        if step == 0:
+            msd = model.state_dict()
+            for k in w1:
+                assert maxerr(msd[k].cpu(), w1[k]) < TOL, k
+    msd = model.state_dict()
+    for k in w3:
+        assert maxerr(msd[k].cpu(), w3[k]) < 2e-4, k

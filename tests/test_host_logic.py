@@ -115,12 +115,6 @@ def test_shard_bounds_cover_and_align():
             assert all(i0 % 4 == 0 for i0, i1 in spans if i1 > i0)     # non-empty shards start float4-aligned
 
 
-def test_fused_trainer_rejects_l2():
-    m = srfrd_amd.SASRec(10, 5, 50, 0.0, 1, 1, "cpu")
-    with pytest.raises(NotImplementedError):
-        srfrd_amd.FusedTrainer(m, 4, 5, l2_emb=0.1)
-
-
 def test_reference_checkpoint_roundtrip(tmp_path):
     """a reference-format checkpoint (torch.save of the state_dict, trainer.py:409-411) loads strictly, safely."""
     g, sd, _ = load_golden("SRFU_R")

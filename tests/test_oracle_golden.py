@@ -91,3 +91,27 @@ def test_rank_metric():
     assert r.tolist() == [int((-logits[i]).argsort().argsort()[0]) for i in range(2)]
     ndcg, hr = O.hr_ndcg_at_10(r)
     assert hr == 1.0 and abs(ndcg - (1 / np.log2(3) + 1) / 2) < 1e-12
+
+
+def test_l2_emb_train_step_matches_reference():
+    """reference trainer.py:39 with config.l2_emb = 0.05: loss += l2_emb * torch.norm(p) for every parameter tensor
+    (tests/golden/SRFRN_l2.npz, make_golden.py --l2): loss curve, gradients, weights after 1 and 3 Adam steps."""
+    g, sd, batch = load_golden("SRFRN", l2=True)
+    cfg = golden_cfg("SRFRN")
+    l2 = float(g["l2_emb"])
+    assert l2 == 0.05
+    loss, grads, *_ = O.grads_of(cfg, sd, batch, l2_emb=l2)
+    assert abs(float(loss) - float(g["loss0"])) < 5e-6
+    gg = sub(g, "g/")
+    for k in gg:
+        np.testing.assert_allclose(grads[k].numpy(), gg[k].numpy(), atol=TOL, rtol=0, err_msg=k)
+    opt = O.Adam(sd)
+    w1, w3 = sub(g, "w1/"), sub(g, "w3/")
+    for step in range(3):
+        loss = O.train_step(cfg, sd, opt, batch, train=False, l2_emb=l2)
+        assert abs(float(loss) - float(g[f"loss{step}"])) < 1e-5
+        if step == 0:
+            for k in w1:
+                np.testing.assert_allclose(sd[k].numpy(), w1[k].numpy(), atol=2e-5, rtol=0, err_msg=k)
+    for k in w3:
+        np.testing.assert_allclose(sd[k].numpy(), w3[k].numpy(), atol=1e-4, rtol=0, err_msg=k)

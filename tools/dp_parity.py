@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--batch", type=int, default=24, help="global batch (split evenly over the ranks)")
     ap.add_argument("--seq-len", type=int, default=50)
+    ap.add_argument("--l2-emb", type=float, default=0.0, help="reference trainer.py:39 with a non-zero config.l2_emb")
     args = ap.parse_args()
     world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -92,7 +93,7 @@ def main():
     post_flat, grads, ref_loss = torch.zeros(K, n_flat, device=dev), [], []
     if rank == 0:
         ref = make_model()
-        rt = srfrd_amd.FusedTrainer(ref, Bg, L, seed=17, use_graph=False, process_group=solo)
+        rt = srfrd_amd.FusedTrainer(ref, Bg, L, seed=17, use_graph=False, process_group=solo, l2_emb=args.l2_emb)
         assert rt.world == 1 and rt.mode == "single"
         rt.refresh()
         for i in range(K):
@@ -112,7 +113,7 @@ def main():
             dist.broadcast(c, src=0)
             t.copy_(c)
     # ---- the data-parallel trainer, every step from the recorded state
-    tr = srfrd_amd.FusedTrainer(model, Bl, L, seed=17, use_graph=not args.eager, exchange=args.exchange)
+    tr = srfrd_amd.FusedTrainer(model, Bl, L, seed=17, use_graph=not args.eager, exchange=args.exchange, l2_emb=args.l2_emb)
     assert tr.world == world and tr.mode == args.exchange
     dp_loss, dp_post = [], []
     for i in range(K):
