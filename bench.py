@@ -233,6 +233,7 @@ def main():
         torch.cuda.synchronize()
 
     log("model + batches ready")
+    tr.spin_up()          # device to steady state inside a snapshot (no training: state restored); then W warm-up steps
     for i in range(args.warmup):
         step_i(i)
     barrier()

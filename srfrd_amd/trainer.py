@@ -233,9 +233,14 @@ class FusedTrainer:
                 self._enqueue_update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        for dst, src in zip(keep, snap):
-            dst.copy_(src)
-        self.model.pack_weights()             # the warm-up step re-packed the stepped weights: restore that too
+
+        def restore():
+            for dst, src in zip(keep, snap):
+                dst.copy_(src)
+            self.model.pack_weights()         # the warm-up step re-packed the stepped weights: restore that too
+            self.model.refresh_bf16_table()   # ... and re-derived the bf16 shadow of the stepped table (if one is in use)
+
+        restore()
         # thread_local capture mode: a collective backend's watchdog thread may touch the HIP runtime while we capture
 
         def graph_of(fn):
@@ -255,8 +260,41 @@ class FusedTrainer:
             self._graph_a = [graph_of(lambda k=k: self._enqueue_bwd(k)) for k in range(self.slots)]
             self._graph_u = graph_of(self._enqueue_shard_update)
             self._graph_b = graph_of(self._enqueue_shard_finish)
+        # The first replay of a graph also uploads it to the device (tens of microseconds, once per graph - and there is one
+        # graph per input slot): replay each once here, inside the snapshot, so that no step pays for it.  (Compute graphs
+        # only: no collective is involved, every rank does the same.)
+        for gs in (self._graph_f, self._graph_a, [self._graph_u], [self._graph_b]):
+            for g in (gs or []):
+                if g is not None:
+                    g.replay()
+        torch.cuda.synchronize()
+        restore()
 
     # ---- public -------------------------------------------------------------------------------
+    def spin_up(self, replays: int = 200):
+        """Bring the device to its steady state (clocks, caches, TLBs of the step's buffers) without training: replays the
+        captured single-rank step `replays` times on whatever slot 0 holds, inside a snapshot - parameters, optimizer
+        moments, step counter and dropout seed are restored afterwards, so the next step is the one it would have been.
+        (The first hundred steps after start-up run ~4 % slower than the rest; a short measurement that wants the
+        steady-state rate calls this first.  No-op without graphs or in data parallel.)"""
+        if not self.use_graph or self.mode != "single":
+            return
+        if not self._fresh:
+            self.refresh()
+        if self._graph_a is None:
+            self._capture()
+        torch.cuda.synchronize()
+        keep = [self.flat, self.m, self.v, self.state, self.grad, self.stats]
+        snap = [t.clone() for t in keep]
+        for _ in range(int(replays)):
+            self._graph_a[0].replay()
+        torch.cuda.synchronize()
+        for dst, src in zip(keep, snap):
+            dst.copy_(src)
+        self.model.pack_weights()
+        self.model.refresh_bf16_table()
+        torch.cuda.synchronize()
+
     def refresh(self):
         """Re-derive everything the step keeps derived from the parameters (the MFMA-fragment-ordered weight copy).  Call
         after modifying parameters from outside the trainer - ``load_state_dict``, a re-initialisation, a manual edit;

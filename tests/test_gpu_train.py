@@ -455,3 +455,31 @@ def test_fused_trainer_l2_emb_matches_golden(graph):
     msd = model.state_dict()
     for k in w3:
         assert maxerr(msd[k].cpu(), w3[k]) < 2e-4, k
+
+
+def test_spin_up_leaves_the_training_trajectory_untouched():
+    """FusedTrainer.spin_up() replays the captured step inside a snapshot (bench.py uses it to reach the device's steady
+    state before a short timed region): parameters, moments, step counter and dropout seed must come back bit for bit, so
+    the steps that follow are the ones that would have run without it."""
+    import srfrd_amd
+    from tests.gpu_util import build_model, random_sd
+    cfg = _cfg50("SRFRN", dropout=0.5)
+    sd = random_sd(cfg, 21)
+    B = 16
+    batches = [srfrd_amd.synthetic_batch(400, 50, B, seed=9, index=i, device="cuda", packed=True)[1] for i in range(3)]
+    outs = []
+    for spin in (False, True):
+        model = build_model(cfg, {k: v.clone() for k, v in sd.items()}).train()
+        tr = srfrd_amd.FusedTrainer(model, batch_size=B, seq_len=50, seed=77, deterministic=True)
+        if spin:
+            tr.ids_ring[0].copy_(batches[2])
+            tr.spin_up(7)
+        losses = [float(tr.step_packed(b).cpu()) for b in batches]
+        outs.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, tr.state_dict()))
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+    s0, s1 = outs[0][2]["state"], outs[1][2]["state"]
+    for i in s0:
+        for name in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(s0[i][name], s1[i][name]), (i, name)
