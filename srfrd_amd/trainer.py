@@ -276,8 +276,9 @@ class FusedTrainer:
         captured single-rank step `replays` times on whatever slot 0 holds, inside a snapshot - parameters, optimizer
         moments, step counter and dropout seed are restored afterwards, so the next step is the one it would have been.
         (The first hundred steps after start-up run ~4 % slower than the rest; a short measurement that wants the
-        steady-state rate calls this first.  No-op without graphs or in data parallel.)"""
-        if not self.use_graph or self.mode != "single":
+        steady-state rate calls this first.  No-op without graphs.  In data parallel the local graphs are replayed without
+        the collectives between them - every rank does the same, nothing is exchanged, everything is restored.)"""
+        if not self.use_graph:
             return
         if not self._fresh:
             self.refresh()
@@ -286,8 +287,11 @@ class FusedTrainer:
         torch.cuda.synchronize()
         keep = [self.flat, self.m, self.v, self.state, self.grad, self.stats]
         snap = [t.clone() for t in keep]
+        seq = [g[0] if isinstance(g, list) else g for g in (self._graph_f, self._graph_a, self._graph_u, self._graph_b)
+               if g is not None]
         for _ in range(int(replays)):
-            self._graph_a[0].replay()
+            for g in seq:
+                g.replay()
         torch.cuda.synchronize()
         for dst, src in zip(keep, snap):
             dst.copy_(src)
