@@ -57,6 +57,14 @@ def test_two_ranks_l2_emb(exchange):
     assert rep["max_loss_diff"] < 1e-5 and rep["weight_violations"] == 0 and rep["replicas_bit_identical"]
 
 
+@pytest.mark.parametrize("exchange", ["sharded", "allreduce"])
+def test_two_ranks_spin_up_changes_nothing(exchange):
+    """FusedTrainer.spin_up() in data parallel (local graphs, no collective, snapshot restored) before every step"""
+    rep = run_dp_parity("--exchange", exchange, "--spin-up")
+    assert rep["world"] == 2 and rep["ok"]
+    assert rep["max_loss_diff"] < 1e-5 and rep["weight_violations"] == 0 and rep["replicas_bit_identical"]
+
+
 def test_three_ranks_srfrn_sharded():
     """uneven shard edges (n_flat is not a multiple of 3 x 4) and the [item || fake] kind"""
     rep = run_dp_parity("--exchange", "sharded", "--kind", "SRFRN", "--batch", "24", nproc=3)

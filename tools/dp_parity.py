@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--batch", type=int, default=24, help="global batch (split evenly over the ranks)")
     ap.add_argument("--seq-len", type=int, default=50)
     ap.add_argument("--l2-emb", type=float, default=0.0, help="reference trainer.py:39 with a non-zero config.l2_emb")
+    ap.add_argument("--spin-up", action="store_true", help="call FusedTrainer.spin_up() before every step (must change nothing)")
     args = ap.parse_args()
     world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -127,6 +128,8 @@ def main():
             tr.m.copy_(pre_m[i]); tr.v.copy_(pre_v[i])
         tr.state.copy_(pre_state[i])
         tr.refresh()
+        if args.spin_up:
+            tr.spin_up(3)
         dp_loss.append(float(tr.step_packed(batches[i][:, rank * Bl:(rank + 1) * Bl].contiguous()).cpu()))
         dp_post.append(model.flat_parameters().detach().clone())
     tr.check()
