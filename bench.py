@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- sequences/sec of the fused SRFRD train step (reference trainer.py:27-41) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+        N > 1: one rank per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) this process IS a rank; started
+        plainly, it launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself as a child (before any
+        GPU call), relays the child's output and exits with its status.
 
 Workload (BASELINE.json configs[1], "C2"): SASRec (discriminator off), 50 000 items, seq_len 50, batch 512 per GPU,
 hidden 50, 2 blocks, 1 head, dropout 0.5, Adam(1e-3, betas=(0.9, 0.98)), fp32 arithmetic, synthetic ids already in HBM.
@@ -87,22 +90,57 @@ def host_cores():
 
 
 def pmc_traffic(kernel_c_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    separate passes, read side doubled as MI355X_MICROARCH.md prescribes for gfx950); None if no profile is committed."""
-    ks = None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    """(HBM bytes per launch of the dominant kernel, source file) from the committed rocprofv3 PMC passes (FETCH_SIZE /
+    WRITE_SIZE, separate passes, read side doubled as MI355X_MICROARCH.md prescribes for gfx950) - NOT measured in this run:
+    counters need their own profiler passes; (None, None) if no profile is committed."""
+    ks = src = None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             ks = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+            src = "profiles/" + name
             break
         except Exception:
             continue
     if ks is None:
-        return None
+        return None, None
     stem = kernel_c_name.replace("srfrd_", "")                      # srfrd_encoder_bwd -> encoder_bwd[_slots]_kernel<...>
     for name, d in ks.items():
         if name.startswith(stem) and "_kernel" in name and "hbm_bytes_per_launch" in d and "<0, 0, 0>" not in name:
-            return d["hbm_bytes_per_launch"]["total"]
-    return None
+            return d["hbm_bytes_per_launch"]["total"], src
+    return None, None
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the N ranks as a child process.  Nothing in
+    THIS process has touched the GPU (an exec / fork after HIP initialisation is not allowed on this pool); the child's
+    stderr passes through, rank 0's JSON line is relayed on stdout, the exit status is the child's."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()           # (counting devices does not initialise HIP)
+    backend = os.environ.get("SRFRD_DIST_BACKEND", "nccl")
+    if n_dev < args.gpus and backend == "nccl":
+        raise SystemExit(f"--gpus {args.gpus}: this node exposes {n_dev} GPU(s); refusing to report a smaller job under that name "
+                         "(SRFRD_DIST_BACKEND=gloo rehearses the multi-rank path on fewer GPUs, labelled as such)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"launching {args.gpus} ranks: {' '.join(cmd)}")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for ln in child.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    raise SystemExit(rc)
 
 
 def metric_parity():
@@ -188,18 +226,23 @@ def main():
     ap.add_argument("--autograd", action="store_true", help="exploration: time the module-level drop-in path (model(...) -> BCE -> "
                     "loss.backward() -> torch.optim.Adam) instead of FusedTrainer")
     ap.add_argument("--predict", action="store_true", help="time forward + full-catalog top-10 instead of the train step")
+    ap.add_argument("--spin-up", type=int, default=200, help="untimed replays of the captured step inside a state snapshot before the "
+                    "W warm-up steps (steady-state clocks / caches; state restored bit for bit; reported in config.spin_up_replays)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                      # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line must report the job that ran")
     n_dev = torch.cuda.device_count()
     local = local % max(n_dev, 1)             # rehearsal of the multi-rank path on a one-GPU box (SRFRD_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SRFRD_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
@@ -233,7 +276,9 @@ def main():
         torch.cuda.synchronize()
 
     log("model + batches ready")
-    tr.spin_up()          # device to steady state inside a snapshot (no training: state restored); then W warm-up steps
+    # device to steady state inside a snapshot (no training: state restored), then the W warm-up steps asked for.  The replays
+    # are untimed work ahead of the timed region and are REPORTED (config.spin_up_replays); --spin-up 0 turns them off.
+    tr.spin_up(args.spin_up)
     for i in range(args.warmup):
         step_i(i)
     barrier()
@@ -266,6 +311,8 @@ def main():
         achieved = dom_flops / dom_s / 1e12 if dom_s > 0 else 0.0
         step_bytes = algorithmic_bytes_per_step(cfg["n_items"], L, B, lay.D, lay.d_item, lay.n_blocks, lay.n_dense)
         ms = elapsed / args.steps * 1e3
+        traffic, traffic_src = pmc_traffic(dom)
+        valid = float((batches[0][0] != 0).float().mean())       # non-pad share of the B x L token grid (lengths ~ U[2, L])
         out = {
             "metric": "sequences/sec", "value": world * B * args.steps / elapsed, "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -273,10 +320,12 @@ def main():
             "config": {"workload": "C2: SASRec train step (fwd + masked BCE + bwd + dense Adam), 50k items, seq_len 50, "
                                    "batch 512 per GPU, hidden 50, 2 blocks, 1 head, dropout 0.5",
                        "global_batch": world * B, "seq_len": L, "n_items": cfg["n_items"],
-                       "parallelism": f"dp{world}", "exchange": tr.mode, "graph": not args.no_graph, "table_scatter": "sort + ordered sums" if args.deterministic else "float atomics",
+                       "parallelism": f"dp{world}", "ranks": dist.get_world_size() if world > 1 else 1, "backend": "rccl" if backend == "nccl" else backend,
+                       "exchange": tr.mode, "graph": not args.no_graph, "graph_form": tr.graph_form, "spin_up_replays": args.spin_up if not args.no_graph else 0,
+                       "valid_token_fraction": valid, "table_scatter": "sort + ordered sums" if args.deterministic else "float atomics",
                        "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(dom),
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_kernel_ms": kt[dom], "algorithmic_flops_per_launch": dom_flops,
                          "kernel_ms": kt,
                          "step_hbm": {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes,

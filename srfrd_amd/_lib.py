@@ -14,7 +14,8 @@ MAX_BLOCKS = 8
 MAX_D = 64
 KINDS = {"SASRec": 0, "SRFR": 1, "SRFRN": 2, "SRFU_B": 3, "SRFU_F": 4, "SRFU_R": 5}
 _ERR = {-1: "SRFRD_E_ARG (bad argument)", -2: "SRFRD_E_UNSUPPORTED (configuration outside the fused kernels: "
-        "hidden width > 64, num_heads != 1, or sequence too long for the 160 KiB LDS)", -3: "SRFRD_E_DEVICE"}
+        "hidden width > 64, hidden width not divisible by num_heads, a debug tap of a kernel without taps, or a caller-provided "
+        "scratch buffer too small for this sequence length)", -3: "SRFRD_E_DEVICE"}
 
 
 class BlockOff(C.Structure):

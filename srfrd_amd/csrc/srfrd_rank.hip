@@ -300,6 +300,7 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
 constexpr int kWaves16 = 16;                    // waves per workgroup of the bf16 streams
 constexpr int kChunk16 = 512;                   // most item rows of a chunk
+constexpr int kStageSlots16 = 13;               // staging registers per thread: a chunk's rows x copy elements per row <= 13 x 1024
 constexpr int kHS = 72;                         // bf16 row stride of an item row in LDS (64 + 8: rows 144 B apart)
 constexpr int kStream16Lds = 2 * kChunk16 * kHS * 2;
 
@@ -363,7 +364,7 @@ __device__ __forceinline__ void topk_stream16(const TopkArgs& a, BEG&& begin, EL
   // ---- item chunks: table -> registers -> LDS; thread t owns copy elements t, t + nthr, ... of the chunk
   const bool dw = !SPLIT_E && (di & 1) == 0;           // bf16 rows that are whole dwords (d_item even): 4-byte copies
   const int rw = SPLIT_E ? di : (dw ? di >> 1 : di);   // copy elements per row
-  constexpr int SIT = 13;                              // 512 x 25 dwords / 256 x 50 floats over 1024 threads
+  constexpr int SIT = kStageSlots16;                   // 512 x 25 dwords / 256 x 50 floats over 1024 threads
   uint32_t sv[SIT];
   // (the thread index is laundered at every use: its per-slot row / column split is cheap to redo and would otherwise
   // sit in 26 registers for the whole launch)
@@ -1023,6 +1024,11 @@ extern "C" int srfrd_logits_topk(const srfrd_layout* lay, const void* item_table
     int groups = (user_tiles + kWaves16 * nu - 1) / (kWaves16 * nu);
     int crows = bf16_tab ? kChunk16 : 256;
     if ((lay->d_item & 1) != 0 || ((n_rows + crows - 1) / crows) * groups < 2 * (int64_t)cu) crows = 256;
+    // a chunk is staged through kStageSlots16 registers per thread: rows x copy elements per row must fit them (a 512-row
+    // chunk of a bf16 table does up to d_item 52; wider rows take 256-row chunks - rows beyond the slots would never be copied)
+    const int64_t copy_w = bf16_tab ? ((lay->d_item & 1) == 0 ? lay->d_item >> 1 : lay->d_item) : lay->d_item;
+    if ((int64_t)crows * copy_w > (int64_t)kStageSlots16 * kWaves16 * 64) crows = 256;
+    if ((int64_t)crows * copy_w > (int64_t)kStageSlots16 * kWaves16 * 64) return SRFRD_E_UNSUPPORTED;
     int64_t nch = (n_rows + crows - 1) / crows;
     if (nch * groups < cu && nu == 2) { nu = 1; groups = (user_tiles + kWaves16 - 1) / kWaves16; }
     int per_group = cu / groups < 1 ? 1 : cu / groups;

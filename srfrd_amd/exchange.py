@@ -20,8 +20,16 @@ tensors, so the same shard arithmetic runs on all-reduce + per-shard broadcasts 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def exchange_forced() -> bool:
+    """SRFRD_FORCE_EXCHANGE=1: take the data-parallel code paths (collectives, shard arithmetic, split step) in a process
+    group of ONE rank too - how the RCCL arms are exercised on a one-GPU box (tests/test_gpu_nccl_single.py)."""
+    return os.environ.get("SRFRD_FORCE_EXCHANGE", "") == "1"
 
 
 def shard_bounds(n: int, world: int, rank: int, align: int = 4):
@@ -43,7 +51,7 @@ class GradExchange:
 
     def __init__(self, n: int, group=None):
         self.group = group
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or exchange_forced())
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.n = int(n)

@@ -102,16 +102,22 @@ def _fwd_setup(ctx, inputs, output):
     (params, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, model_key, dropout_p, seed, seq0, save) = inputs
     if not save:
         raise RuntimeError("srfrd::encoder_fwd needs save=True to be differentiated (checkpoints for the backward)")
-    ctx.ids = (input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake)
+    # outputs and id tensors through save_for_backward (no output -> grad_fn -> ctx -> output cycle: the checkpoints - B x
+    # (n_blocks + 1) x L x D floats - are released by refcount after the backward, and torch's version counters guard them);
+    # only ints / flags stay on ctx
+    ids = (input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake)
+    ctx.id_present = tuple(t is not None for t in ids)
     ctx.meta = (model_key, dropout_p, seed, seq0, len(params))
-    ctx.saved = output
+    ctx.save_for_backward(*output, *[t for t in ids if t is not None])
 
 
 def _fwd_backward(ctx, grads):
     model_key, p, seed, seq0, n_params = ctx.meta
     m = _model(model_key)
-    hidden, pl, nl, sx, sh, sa = ctx.saved
-    inp, fk, pos, pfk, neg, nfk = ctx.ids
+    saved = ctx.saved_tensors
+    hidden, pl, nl, sx, sh, sa = saved[:6]
+    rest = iter(saved[6:])
+    inp, fk, pos, pfk, neg, nfk = (next(rest) if present else None for present in ctx.id_present)
     d_hidden, d_pl, d_nl = grads[0], grads[1], grads[2]
     gflat = torch.ops.srfrd.encoder_bwd(inp, fk, pos, pfk, neg, nfk, model_key, p, seed, seq0, hidden, pl, nl, sx, sh, sa,
                                         None if d_hidden is None else d_hidden.contiguous(),

@@ -48,7 +48,8 @@ def topk_merge(cand_idx: torch.Tensor, cand_val: torch.Tensor, k: int):
 class ShardedRanker:
     def __init__(self, model, n_shards: int | None = None, process_group=None):
         self.model, self.group = model, process_group
-        self.dist_on = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        from .exchange import exchange_forced
+        self.dist_on = dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1 or exchange_forced())
         self.world = dist.get_world_size(process_group) if self.dist_on else 1
         self.rank = dist.get_rank(process_group) if self.dist_on else 0
         self.n_shards = self.world if self.dist_on else int(n_shards or 1)

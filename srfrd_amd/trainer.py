@@ -20,6 +20,7 @@ mean-over-all-targets loss of trainer.py:36-38 (not an average of per-rank means
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -61,7 +62,7 @@ class FusedTrainer:
         self.world, self.rank = self.ex.world, self.ex.rank
         if exchange not in ("sharded", "allreduce"):
             raise ValueError("exchange must be 'sharded' or 'allreduce'")
-        self.mode = "single" if self.world == 1 else exchange
+        self.mode = exchange if self.ex.on else "single"      # (ex.on: world > 1, or a forced exchange in a group of one)
         lay, B, L = self.lay, self.B, self.L
         f32 = dict(device=dev, dtype=torch.float32)
         if self.mode == "sharded":
@@ -114,7 +115,9 @@ class FusedTrainer:
         check(_lib.lib().srfrd_step_begin(ptr(self.state), self.lr, self.betas[0], self.betas[1],
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "srfrd_step_begin")
         self.use_graph = bool(use_graph)
-        self._graph_a = self._graph_b = self._graph_f = self._graph_u = None
+        self._graph_a = self._graph_b = self._graph_f = self._graph_u = self._graph_one = None
+        self.graph_form = None           # "one" | "split" once captured (data parallel: one graph with the collectives inside, or graphs around them)
+        self.graph_capture_error = None
         self.steps_done = 0
         self.err = torch.zeros(1, device=dev, dtype=torch.int32)   # srfrd_check_ids word of step() / step_packed() inputs
         self._fresh = False      # packed weights known to match the parameters (see refresh())
@@ -188,7 +191,7 @@ class FusedTrainer:
                                       self.n_flat, self.n_tab, self.n_tab, self.lr, self.betas[0], self.betas[1], self.eps,
                                       ptr(self.state), ptr(self.stats), ptr(self.packed), ptr(self.model._table16), st),
               "srfrd_adam_pack_step")
-        if self.world > 1:
+        if self.mode != "single":
             check(L_.srfrd_loss_finalize(ptr(self.stats), ptr(self.loss), st), "srfrd_loss_finalize")
         if self.l2 != 0.0:
             self.loss.add_(self.l2buf[1:2])
@@ -216,6 +219,23 @@ class FusedTrainer:
         check(L_.srfrd_loss_finalize(ptr(self.stats), ptr(self.loss), st), "srfrd_loss_finalize")
         if self.l2 != 0.0:
             self.loss.add_(self.l2buf[1:2])
+
+    def _enqueue_dp_step(self, slot: int = 0):
+        """the whole data-parallel step on the current stream, collectives included (eager, or under capture with RCCL)"""
+        if self.mode == "allreduce":
+            self._enqueue_compute(slot)
+            self.ex.all_reduce(self.grad)
+            self._enqueue_update()
+        else:
+            self._enqueue_fwd(slot)
+            h = self.ex.all_reduce_stats(self.stats)               # 16 bytes, in flight under the backward
+            self._enqueue_bwd(slot)
+            self.ex.reduce_scatter(self.grad, self.recv)
+            if h is not None:
+                h.wait()
+            self._enqueue_shard_update()
+            self.ex.all_gather(self.flat_pad)
+            self._enqueue_shard_finish()
 
     def _capture(self):
         # warm-up on a side stream (sets the LDS attributes, loads code objects), then capture
@@ -250,7 +270,24 @@ class FusedTrainer:
             return g
 
         # one graph per input slot (the kernels' id pointers are baked in)
-        if self.mode == "single":
+        self.graph_form = "one" if self.mode == "single" else "split"
+        if self.mode != "single" and self.ex.native and os.environ.get("SRFRD_DP_SPLIT_GRAPHS", "") != "1":
+            # RCCL collectives are stream work: the WHOLE data-parallel step - compute, collectives, sharded Adam, re-pack -
+            # goes into ONE graph per slot, so a step is one host launch and nothing on the host sits between the kernels and
+            # the collectives.  (ProcessGroupNCCL forks its internal stream off the capturing one and joins it back: the
+            # statistics all-reduce stays concurrent with the backward inside the graph.)  If this torch / RCCL pair refuses
+            # the capture, the step falls back to the split form below; `graph_form` says which one runs.
+            try:
+                self._graph_one = [graph_of(lambda k=k: self._enqueue_dp_step(k)) for k in range(self.slots)]
+                self.graph_form = "one"
+            except Exception as e:                      # noqa: BLE001 - any capture failure selects the split form
+                self._graph_one = None
+                self.graph_capture_error = repr(e)
+                torch.cuda.synchronize()
+                restore()
+        if self.graph_form == "one" and self.mode != "single":
+            pass
+        elif self.mode == "single":
             self._graph_a = [graph_of(lambda k=k: (self._enqueue_compute(k), self._enqueue_update())) for k in range(self.slots)]
         elif self.mode == "allreduce":
             self._graph_a = [graph_of(lambda k=k: self._enqueue_compute(k)) for k in range(self.slots)]
@@ -263,10 +300,14 @@ class FusedTrainer:
         # The first replay of a graph also uploads it to the device (tens of microseconds, once per graph - and there is one
         # graph per input slot): replay each once here, inside the snapshot, so that no step pays for it.  (Compute graphs
         # only: no collective is involved, every rank does the same.)
-        for gs in (self._graph_f, self._graph_a, [self._graph_u], [self._graph_b]):
-            for g in (gs or []):
-                if g is not None:
-                    g.replay()
+        if self._graph_one is None:
+            for gs in (self._graph_f, self._graph_a, [self._graph_u], [self._graph_b]):
+                for g in (gs or []):
+                    if g is not None:
+                        g.replay()
+        else:
+            for g in self._graph_one:       # (holds collectives: every rank replays the same graphs in the same order)
+                g.replay()
         torch.cuda.synchronize()
         restore()
 
@@ -276,19 +317,23 @@ class FusedTrainer:
         captured single-rank step `replays` times on whatever slot 0 holds, inside a snapshot - parameters, optimizer
         moments, step counter and dropout seed are restored afterwards, so the next step is the one it would have been.
         (The first hundred steps after start-up run ~4 % slower than the rest; a short measurement that wants the
-        steady-state rate calls this first.  No-op without graphs.  In data parallel the local graphs are replayed without
-        the collectives between them - every rank does the same, nothing is exchanged, everything is restored.)"""
+        steady-state rate calls this first.  No-op without graphs.  In data parallel every rank replays the same graphs the same
+        number of times: the one-graph form with its collectives inside, the split form's local graphs without the collectives
+        between them; everything is restored.)"""
         if not self.use_graph:
             return
         if not self._fresh:
             self.refresh()
-        if self._graph_a is None:
+        if self._graph_a is None and self._graph_one is None:
             self._capture()
         torch.cuda.synchronize()
         keep = [self.flat, self.m, self.v, self.state, self.grad, self.stats]
         snap = [t.clone() for t in keep]
-        seq = [g[0] if isinstance(g, list) else g for g in (self._graph_f, self._graph_a, self._graph_u, self._graph_b)
-               if g is not None]
+        if self._graph_one is not None:      # (collectives inside: every rank replays the same number of times)
+            seq = [self._graph_one[0]]
+        else:
+            seq = [g[0] if isinstance(g, list) else g for g in (self._graph_f, self._graph_a, self._graph_u, self._graph_b)
+                   if g is not None]
         for _ in range(int(replays)):
             for g in seq:
                 g.replay()
@@ -375,7 +420,7 @@ class FusedTrainer:
         # step size, bias correction and dropout seed of the NEXT step (t = steps_done + 1), as after an uninterrupted run.
         # (The captured graphs bake lr / betas in as launch arguments: they are re-captured.)
         check(_lib.lib().srfrd_step_begin(ptr(self.state), self.lr, self.betas[0], self.betas[1], self._stream()), "srfrd_step_begin")
-        self._graph_a = self._graph_b = self._graph_f = self._graph_u = None
+        self._graph_a = self._graph_b = self._graph_f = self._graph_u = self._graph_one = None
         self._fresh = False
 
     def _check_slot(self, slot: int = 0):
@@ -422,26 +467,31 @@ class FusedTrainer:
         if not self._fresh:
             self.refresh()
         g = self.use_graph
-        if g and self._graph_a is None:
+        if g and self._graph_a is None and self._graph_one is None:
             self._capture()
-        if self.mode == "single":
-            if g:
-                self._graph_a[slot].replay()
-            else:
+        if not g:
+            if self.mode == "single":
                 self._enqueue_compute(slot)
                 self._enqueue_update()
-        elif self.mode == "allreduce":
-            self._graph_a[slot].replay() if g else self._enqueue_compute(slot)
+            else:
+                self._enqueue_dp_step(slot)
+        elif self._graph_one is not None:          # data parallel, collectives captured: ONE host launch per step
+            self._graph_one[slot].replay()
+        elif self.mode == "single":
+            self._graph_a[slot].replay()
+        elif self.mode == "allreduce":             # split form: graphs around the host-launched collectives
+            self._graph_a[slot].replay()
             self.ex.all_reduce(self.grad)
-            self._graph_b.replay() if g else self._enqueue_update()
+            self._graph_b.replay()
         else:
-            self._graph_f[slot].replay() if g else self._enqueue_fwd(slot)
+            self._graph_f[slot].replay()
             h = self.ex.all_reduce_stats(self.stats)               # 16 bytes, in flight under the backward
-            self._graph_a[slot].replay() if g else self._enqueue_bwd(slot)
+            self._graph_a[slot].replay()
             self.ex.reduce_scatter(self.grad, self.recv)
-            h.wait()
-            self._graph_u.replay() if g else self._enqueue_shard_update()
+            if h is not None:
+                h.wait()
+            self._graph_u.replay()
             self.ex.all_gather(self.flat_pad)
-            self._graph_b.replay() if g else self._enqueue_shard_finish()
+            self._graph_b.replay()
         self.steps_done += 1
         return self.loss

@@ -46,7 +46,7 @@ def test_lds_capability_query():
     f50, b50 = _lib.lds_bytes(lay, 50)
     assert 0 < f50 <= 160 * 1024 and 0 < b50 <= 160 * 1024
     f100, b100 = _lib.lds_bytes(lay, 100)
-    assert f100 > 0 and b100 == 0                         # round 1: backward is LDS-resident up to 64 positions
+    assert f100 > 0 and b100 == 0                         # (first-generation layouts: the slot / chunk backward kernels report through srfrd_scratch_floats)
     assert _lib.lds_bytes(lay, 200) == (0, 0)
     assert _lib.scratch_floats(lay, 512, 50) == (0, 0)             # LDS-resident
     f200, b200 = _lib.scratch_floats(lay, 512, 200)                 # long-sequence build: global scratch per workgroup

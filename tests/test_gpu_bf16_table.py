@@ -80,3 +80,34 @@ def test_bf16_table_fused_training_keeps_the_shadow_current(graph):
     # switching the shadow off returns to fp32 gathers
     model.use_bf16_table(False)
     assert not model.bf16_table
+
+
+@pytest.mark.parametrize("hidden", [64, 54, 51])
+def test_wide_bf16_rows_rank_like_fp64_on_a_large_catalog(hidden):
+    """hidden 54..64 over the bf16 shadow on a catalog large enough for the 512-row chunks of the streamed ranking (ADVICE
+    round 2): a 512-row chunk of such rows does not fit the staging registers (13 x 1024 copy slots), the launcher must
+    take 256-row chunks - with 512 the rows past slot 13312 of every chunk were never copied and stale rows were ranked.
+    51 = the widest odd width (2-byte copies, 256-row chunks).  Property check against torch.topk in fp64 on the GPU, as
+    test_c5_size_one_million_items_property does (the oracle cannot rank 320k items x 256 users in seconds)."""
+    import srfrd_amd
+    torch.manual_seed(3)
+    I, L, B, k = 320_000, 20, 256, 10
+    m = srfrd_amd.SASRec(I, L, hidden, 0.0, 2, 1, "cuda")
+    for _, p in m.named_parameters():
+        if p.dim() >= 2:
+            torch.nn.init.xavier_normal_(p.data)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        m.item_emb.weight.mul_(30.0)
+    m.use_bf16_table()
+    _, seq, rsq, *_ = srfrd_amd.synthetic_batch(I, L, B, seed=8, device="cuda")
+    idx, val = m.topk(None, seq, None, k=k)
+    with torch.no_grad():
+        h = m(None, seq, None)[0][:, -1].double()
+        scores = h @ m.item_emb.weight.to(torch.bfloat16).double().T
+        scores[:, 0] = -float("inf")
+        tv, ti = torch.topk(scores, k + 1, dim=1)
+    assert float((val.double() - tv[:, :k]).abs().max()) < 1e-4
+    safe = ((tv[:, :-1] - tv[:, 1:]).abs() > 1e-5).all(dim=1)
+    assert int(safe.sum()) > B // 2
+    assert torch.equal(idx[safe], ti[safe][:, :k])
