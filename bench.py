@@ -225,6 +225,8 @@ def main():
     ap.add_argument("--deterministic", action="store_true", help="deterministic item-table scatter (sort + ordered sums) instead of float atomics")
     ap.add_argument("--autograd", action="store_true", help="exploration: time the module-level drop-in path (model(...) -> BCE -> "
                     "loss.backward() -> torch.optim.Adam) instead of FusedTrainer")
+    ap.add_argument("--torch-adam", action="store_true", help="with --autograd: torch.optim.Adam instead of srfrd_amd.Adam")
+    ap.add_argument("--profile-host", action="store_true", help="with --autograd: print a torch.profiler table of the loop (where the host time goes)")
     ap.add_argument("--predict", action="store_true", help="time forward + full-catalog top-10 instead of the train step")
     ap.add_argument("--spin-up", type=int, default=200, help="untimed replays of the captured step inside a state snapshot before the "
                     "W warm-up steps (steady-state clocks / caches; state restored bit for bit; reported in config.spin_up_replays)")
@@ -322,7 +324,8 @@ def main():
                        "global_batch": world * B, "seq_len": L, "n_items": cfg["n_items"],
                        "parallelism": f"dp{world}", "ranks": dist.get_world_size() if world > 1 else 1, "backend": "rccl" if backend == "nccl" else backend,
                        "exchange": tr.mode, "graph": not args.no_graph, "graph_form": tr.graph_form, "spin_up_replays": args.spin_up if not args.no_graph else 0,
-                       "valid_token_fraction": valid, "table_scatter": "sort + ordered sums" if args.deterministic else "float atomics",
+                       "valid_token_fraction": valid, "sequence_schedule": {0: "none", 1: "static length order", 2: "dynamic per-CU pairing"}[tr.sched_mode],
+                       "table_scatter": "sort + ordered sums" if args.deterministic else "float atomics",
                        "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -397,7 +400,8 @@ def explore(args, cfg, model, dev, rank, quiet=False):
         fn = lambda: model.topk(u, seq, rsq, k=10)
     elif args.autograd:
         # the reference's own loop shape (trainer.py:29-41) on the drop-in modules: custom ops + torch autograd + torch Adam
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98))
+        # srfrd_amd.Adam: torch.optim.Adam's update as one launch over the flat parameter vector (--torch-adam: torch's own)
+        opt = (torch.optim.Adam if getattr(args, "torch_adam", False) else srfrd_amd.Adam)(model.parameters(), lr=1e-3, betas=(0.9, 0.98))
         crit = torch.nn.BCEWithLogitsLoss()
 
         def fn():
@@ -421,6 +425,13 @@ def explore(args, cfg, model, dev, rank, quiet=False):
     for _ in range(args.warmup):
         fn()
     torch.cuda.synchronize()
+    if getattr(args, "profile_host", False):
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40), file=sys.stderr)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fn()
@@ -429,6 +440,7 @@ def explore(args, cfg, model, dev, rank, quiet=False):
     if quiet:
         return el / args.steps * 1e3
     print(json.dumps({"workload": args.workload, "mode": "predict_top10" if args.predict else ("train_step_autograd_path" if args.autograd else "train_step"),
+                      "optimizer": ("torch.optim.Adam" if getattr(args, "torch_adam", False) else "srfrd_amd.Adam") if args.autograd else "fused",
                       "kind": cfg["kind"], "sequences_per_s": B * args.steps / el, "ms_per_step": el / args.steps * 1e3,
                       "batch": B, "seq_len": L, "n_items": cfg["n_items"], "item_table": "bf16 shadow" if cfg.get("bf16_table") else "fp32",
                       "contract_line": False}), flush=True)
@@ -442,7 +454,8 @@ def time_kernels(tr, batches, steps):
     import ctypes as C
     from srfrd_amd import _lib
     from srfrd_amd._lib import check, ptr
-    names = ["srfrd_encoder_fwd", "srfrd_encoder_bwd", "srfrd_reduce_dense"]
+    # (the C entry points the trainer's step calls, in call order; reported under the kernels' plain names)
+    names = (["srfrd_seq_order"] if tr.sched_mode else []) + ["srfrd_encoder_fwd_sched", "srfrd_encoder_bwd_sched", "srfrd_reduce_dense"]
     local_update = tr.mode != "sharded"        # (the sharded update needs the collectives around it: compute kernels only)
     if local_update:
         names.append("srfrd_adam_pack_step")
@@ -482,7 +495,7 @@ def time_kernels(tr, batches, steps):
         ts = sorted(ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(lead, steps))
         ts = [t for t in ts if t <= 3.0 * ts[len(ts) // 2]]
         acc[n] = sum(ts) / len(ts)
-    return acc
+    return {n.replace("_sched", ""): v for n, v in acc.items()}
 
 
 if __name__ == "__main__":

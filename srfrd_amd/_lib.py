@@ -49,6 +49,12 @@ SIGNATURES = {
     "srfrd_encoder_fwd_last": (_i, [_LP, _P, _P, _P, _P, _P, _i, _i, _P, _P, _i64, _P]),
     "srfrd_encoder_bwd": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, _P, _i64, _P, _i, _P]),
+    "srfrd_sched_ints": (_i64, [_i]),
+    "srfrd_seq_order": (_i, [_P, _i, _i, _i, _P, _P]),
+    "srfrd_encoder_fwd_sched": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _i64, _P, _i, _P]),
+    "srfrd_encoder_bwd_sched": (_i, [_LP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _d, _u32, _P, _i64,
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, _P, _i64, _P, _i, _P]),
     "srfrd_table_reduce": (_i, [_P, _P, _P, _i64, _i, _P, _P]),
     "srfrd_aux_floats": (_i64, [_LP, _i, _i]),
     "srfrd_reduce_dense": (_i, [_P, _i, _i64, _P, _P, _i, _P, _P, _P]),

@@ -43,7 +43,22 @@ struct EncArgs {
   float* dbg;
   int dbg_seq;
   int64_t dbg_slot;
+  // ragged kernels (seq_len 50): sequence -> workgroup schedule written by srfrd_seq_order (NULL: b = blockIdx.x, += gridDim.x)
+  int* sched;          // int32 workspace, layout below (kSched*)
+  int sched_mode;      // 0 none, 1 static (workgroup x takes the sorted list's entry perm(x)), 2 dynamic (per-CU pairing by arrival)
+  int sched_set;       // 0: forward's counters, 1: backward's
+  int ragged_off;      // diagnostic: the ragged kernels compute every row (t0 = 0), as the full kernels do
 };
+
+// Schedule workspace (int32), filled by srfrd_seq_order for ONE batch; the counters of both launches are zeroed by it.
+//   [kSchedCnt + 16 set + {0 head, 1 tail, 2 taken}]   dynamic mode counters of launch `set` (0 forward, 1 backward)
+//   [kSchedTicket]                                     arrival ticket of srfrd_seq_order's own workgroups
+//   [kSchedG]                                          pair stride G of the static mode (workgroups per "first round": CUs)
+//   [kSchedArr + 2048 set + cu]                        workgroups arrived on hardware CU slot `cu` in launch `set`
+//   [kSchedLen + b]                                    first non-pad position t0 of sequence b
+//   [kSchedLen + B + i]                                sequence index of rank i, longest (fewest leading pads) first, ties by index
+constexpr int kSchedCnt = 0, kSchedTicket = 32, kSchedG = 33, kSchedArr = 64, kSchedLen = 64 + 2 * 2048;
+__host__ __device__ __forceinline__ int64_t sched_ints(int B) { return kSchedLen + 2ll * B; }
 
 // Checkpoint layout: SEQUENCE-major.  Everything the backward reads back for sequence b is contiguous per buffer -
 // save_x: (nb + 1) blocks of [L][D] at b * (nb + 1) * L * D; save_h1: nb blocks at b * nb * L * D; save_aux
@@ -262,6 +277,26 @@ __device__ __forceinline__ void tap(const EncArgs& a, int b, int slot, const lds
   a.seq0 = seq_index0;
   a.qscale = (float)sqrt(1.0 / (double)(lay->D / lay->n_heads));
   return 0;
+}
+
+// The ragged seq_len-50 pair (srfrd_encoder_fwd_ragged_kernel.inc + srfrd_encoder_bwd_ragged_kernel.inc) exchanges
+// checkpoints that hold only the rows of the computed tiles: a training forward may take the ragged kernel only when the
+// backward of the same (layout, length) will be the ragged one, and vice versa - ONE predicate, asked by both launchers.
+[[maybe_unused]] static bool ragged_pair(const srfrd_layout* lay, int L) {
+  if (lay->D != 50 || lay->n_heads != 1 || L != 50 || lay->n_blocks > SRFRD_MAX_BLOCKS) return false;
+  if (getenv("SRFRD_NO_RAGGED") || getenv("SRFRD_GENERIC") || getenv("SRFRD_NO_LSPEC") || getenv("SRFRD_NO_KSPEC") ||
+      getenv("SRFRD_NO_SLOTS50") || getenv("SRFRD_ROWS_ALWAYS") || getenv("SRFRD_FWD_THREADS") || getenv("SRFRD_BWD_THREADS"))
+    return false;
+  if (lay->kind == SRFRD_SASREC) return true;
+  if ((lay->kind == SRFRD_SRFR || lay->kind == SRFRD_SRFRN) && lay->d_item == 45) return true;
+  return lay->kind >= SRFRD_SRFU_B && lay->d_item == 50;
+}
+// kind_variant of the ragged kernels: 0 SASRec 50 + 0, 1 SRFR 45 + 5, 2 SRFRN 45 + 5, 3 SRFU_* 50 + 0 (kind read at run time)
+[[maybe_unused]] static int ragged_variant(const srfrd_layout* lay) {
+  if (lay->kind == SRFRD_SASREC) return 0;
+  if (lay->kind == SRFRD_SRFR) return 1;
+  if (lay->kind == SRFRD_SRFRN) return 2;
+  return 3;
 }
 
 // launch one instantiation.  The > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) applies to one function on the CURRENT

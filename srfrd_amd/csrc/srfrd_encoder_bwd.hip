@@ -15,6 +15,7 @@ using namespace srfrd;
 extern "C" int srfrd_long_launch_bwd(const void* args, int grid, int threads, int variant, void* stream);   // srfrd_encoder_bwd_long.hip
 extern "C" int srfrd_bwd_slots_launch(const void* args, int grid, int L, int kind_variant, void* stream);    // srfrd_encoder_bwd_slots.hip
 extern "C" int srfrd_bwd_chunks_launch(const void* args, int grid, int kind_variant, void* stream);          // srfrd_encoder_bwd_chunks.hip
+extern "C" int srfrd_bwd_ragged_launch(const void* args, int grid, int kind_variant, void* stream);          // srfrd_encoder_bwd_ragged.hip
 
 // kind_variant of the slot-placed / row-chunked kernels (0 SASRec 50 + 0, 1 SRFR 45 + 5, 2 SRFRN 45 + 5, 3 SRFU_* 50 + 0), or -1
 static int slots_variant(const srfrd_layout* lay) {
@@ -37,16 +38,21 @@ extern "C" int srfrd_bwd_grid(const srfrd_layout* lay, int B, int L) {
   return B < wgs ? B : wgs;
 }
 
-extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
-                                 const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
-                                 const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
-                                 double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
-                                 const float* hidden, const float* pos_logits, const float* neg_logits,
-                                 const float* save_x, const float* save_h1, const float* save_aux, const float* d_hidden,
-                                 const float* d_pos,
-                                 const float* d_neg, int fused_bce, float* grad_table, float* table_contrib, float* grad_slabs,
-                                 float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq, void* stream) {
+static int encoder_bwd_impl(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
+                            const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
+                            const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
+                            double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
+                            const float* hidden, const float* pos_logits, const float* neg_logits,
+                            const float* save_x, const float* save_h1, const float* save_aux, const float* d_hidden,
+                            const float* d_pos,
+                            const float* d_neg, int fused_bce, float* grad_table, float* table_contrib, float* grad_slabs,
+                            float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq, int32_t* sched, int sched_mode,
+                            void* stream) {
   EncArgs a = {};
+  a.sched = sched_mode != 0 ? sched : nullptr;
+  a.sched_mode = a.sched ? sched_mode : 0;
+  a.sched_set = 1;
+  a.ragged_off = getenv("SRFRD_RAGGED_FULL_ROWS") != nullptr;
   int rc = fill_args(a, lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
                      dropout_p, seed, seed_dev, seq_index0);
   if (rc) return rc;
@@ -65,6 +71,11 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table
 #else
   const bool taps = dbg != nullptr;
 #endif
+  if (!taps && ragged_pair(lay, L)) {
+    // seq_len 50, hidden 50: the ragged pair (the forward wrote checkpoints for the rows of the computed tiles only)
+    rc = srfrd_bwd_ragged_launch(&a, grid, ragged_variant(lay), stream);
+    if (rc != SRFRD_E_UNSUPPORTED) return rc;
+  }
   if (two_per_cu(lay, L) && !taps && getenv("SRFRD_NO_SLOTS50") == nullptr && getenv("SRFRD_GENERIC") == nullptr &&
       getenv("SRFRD_NO_LSPEC") == nullptr) {
     // seq_len 50 (fused training step or autograd backward): the slot-placed kernel, two workgroups per CU.  (The switches
@@ -118,5 +129,36 @@ extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table
   if (spec && g.LP == 64) return launch_enc(encoder_bwd_kernel<50, 64, 8>, grid, threads, lds, stream, a);
   if (spec && g.LP == 32) return launch_enc(encoder_bwd_kernel<50, 32, 8>, grid, threads, lds, stream, a);
   return launch_enc(encoder_bwd_kernel<0, 0, 0>, grid, threads, lds, stream, a);
+}
+
+extern "C" int srfrd_encoder_bwd(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
+                                 const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
+                                 const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
+                                 double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
+                                 const float* hidden, const float* pos_logits, const float* neg_logits,
+                                 const float* save_x, const float* save_h1, const float* save_aux, const float* d_hidden,
+                                 const float* d_pos,
+                                 const float* d_neg, int fused_bce, float* grad_table, float* table_contrib, float* grad_slabs,
+                                 float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq, void* stream) {
+  return encoder_bwd_impl(lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L, dropout_p,
+                          seed, seed_dev, seq_index0, hidden, pos_logits, neg_logits, save_x, save_h1, save_aux, d_hidden, d_pos,
+                          d_neg, fused_bce, grad_table, table_contrib, grad_slabs, scratch, scratch_floats, dbg, dbg_seq, nullptr, 0,
+                          stream);
+}
+
+extern "C" int srfrd_encoder_bwd_sched(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
+                                       const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
+                                       const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
+                                       double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
+                                       const float* hidden, const float* pos_logits, const float* neg_logits,
+                                       const float* save_x, const float* save_h1, const float* save_aux, const float* d_hidden,
+                                       const float* d_pos, const float* d_neg, int fused_bce, float* grad_table,
+                                       float* table_contrib, float* grad_slabs, float* scratch, int64_t scratch_floats,
+                                       int32_t* sched, int sched_mode, void* stream) {
+  if (sched_mode < 0 || sched_mode > 2 || (sched_mode != 0 && !sched)) return SRFRD_E_ARG;
+  return encoder_bwd_impl(lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L, dropout_p,
+                          seed, seed_dev, seq_index0, hidden, pos_logits, neg_logits, save_x, save_h1, save_aux, d_hidden, d_pos,
+                          d_neg, fused_bce, grad_table, table_contrib, grad_slabs, scratch, scratch_floats, nullptr, 0, sched,
+                          sched_mode, stream);
 }
 

@@ -51,6 +51,7 @@ using namespace srfrd;
 
 extern "C" int srfrd_long_launch_fwd(const void* args, int grid, int threads, void* stream);   // srfrd_encoder_fwd_long.hip
 extern "C" int srfrd_fwd_rows_launch(const void* args, int kind_variant, int mode, void* stream);   // srfrd_encoder_fwd_rows.hip
+extern "C" int srfrd_fwd_ragged_launch(const void* args, int kind_variant, int train, int grid, void* stream);   // srfrd_encoder_fwd_ragged.hip
 
 extern "C" int64_t srfrd_aux_floats(const srfrd_layout* lay, int B, int L) {
   if (!lay || B <= 0 || L <= 0) return SRFRD_E_ARG;
@@ -105,9 +106,13 @@ static int encoder_fwd_impl(const srfrd_layout* lay, const void* item_table, con
                             double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
                             float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
                             float* save_aux, float* loss_part, float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq,
-                            int last_only, void* stream) {
+                            int last_only, int32_t* sched, int sched_mode, void* stream) {
   EncArgs a = {};
   a.last_only = last_only;
+  a.sched = sched_mode != 0 ? sched : nullptr;
+  a.sched_mode = a.sched ? sched_mode : 0;
+  a.sched_set = 0;
+  a.ragged_off = getenv("SRFRD_RAGGED_FULL_ROWS") != nullptr;
   int rc = fill_args(a, lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
                      dropout_p, seed, seed_dev, seq_index0);
   if (rc) return rc;
@@ -149,6 +154,14 @@ static int encoder_fwd_impl(const srfrd_layout* lay, const void* item_table, con
   const int per_cu = (int)(kLdsLimit / lds) > 2 ? 2 : (int)(kLdsLimit / lds);
   int grid = num_cu() * (per_cu < 1 ? 1 : per_cu);
   if (grid > B) grid = B;
+  // The reference's default geometry: the ragged kernel (rows of the left-padded sequence only).  A forward that writes
+  // training checkpoints takes it exactly when the backward of this (layout, length) will be the ragged one (ragged_pair);
+  // debug taps want every row of every intermediate: the full kernel.
+  if (!dbg && ragged_pair(lay, L)) {
+    const bool train = pos_ids && neg_ids && save_x && loss_part && dropout_p > 0.0 && getenv("SRFRD_NO_TSPEC") == nullptr;
+    rc = srfrd_fwd_ragged_launch(&a, ragged_variant(lay), train ? 1 : 0, grid, stream);
+    if (rc != SRFRD_E_UNSUPPORTED) return rc;
+  }
   // 8 waves per workgroup measured fastest for the forward (95 vs 118 us at C2 with 4 waves)
   const int threads = env_threads("SRFRD_FWD_THREADS", 512);
   // (several attention heads: the generic instantiation only)
@@ -191,7 +204,20 @@ extern "C" int srfrd_encoder_fwd(const srfrd_layout* lay, const void* item_table
                                  void* stream) {
   return encoder_fwd_impl(lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L, dropout_p,
                           seed, seed_dev, seq_index0, hidden, pos_logits, neg_logits, save_x, save_h1, save_aux, loss_part, scratch,
-                          scratch_floats, dbg, dbg_seq, 0, stream);
+                          scratch_floats, dbg, dbg_seq, 0, nullptr, 0, stream);
+}
+
+extern "C" int srfrd_encoder_fwd_sched(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
+                                       const int64_t* input_ids, const int64_t* fake_ids, const int64_t* pos_ids,
+                                       const int64_t* pos_fake, const int64_t* neg_ids, const int64_t* neg_fake, int B, int L,
+                                       double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
+                                       float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
+                                       float* save_aux, float* loss_part, float* scratch, int64_t scratch_floats,
+                                       int32_t* sched, int sched_mode, void* stream) {
+  if (sched_mode < 0 || sched_mode > 2 || (sched_mode != 0 && !sched)) return SRFRD_E_ARG;
+  return encoder_fwd_impl(lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L, dropout_p,
+                          seed, seed_dev, seq_index0, hidden, pos_logits, neg_logits, save_x, save_h1, save_aux, loss_part, scratch,
+                          scratch_floats, nullptr, 0, 0, sched, sched_mode, stream);
 }
 
 extern "C" int srfrd_encoder_fwd_last(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
@@ -199,7 +225,7 @@ extern "C" int srfrd_encoder_fwd_last(const srfrd_layout* lay, const void* item_
                                       float* scratch, int64_t scratch_floats, void* stream) {
   return encoder_fwd_impl(lay, item_table, dense, packed, input_ids, fake_ids, nullptr, nullptr, nullptr, nullptr, B, L, 0.0, 0,
                           nullptr, 0, hidden_last, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, scratch, scratch_floats,
-                          nullptr, 0, 1, stream);
+                          nullptr, 0, 1, nullptr, 0, stream);
 }
 
 extern "C" int srfrd_layout_init(srfrd_layout* lay, int kind, int n_items, int max_len, int d_item, int d_fake,

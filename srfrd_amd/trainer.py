@@ -106,11 +106,19 @@ class FusedTrainer:
         self.hidden = torch.empty(B, L, lay.d_out, **f32)
         self.pl = torch.empty(B, L, **f32)
         self.nl = torch.empty(B, L, **f32)
-        self.save_x = torch.empty(B, lay.n_blocks + 1, L, lay.D, **f32)
-        self.save_h1 = torch.empty(B, lay.n_blocks, L, lay.D, **f32)
-        self.save_aux = torch.empty(_lib.lib().srfrd_aux_floats(C.byref(lay), B, L), **f32)
+        # (zeros, not empty: the ragged kernels write and read only the rows of a sequence's computed tiles; rows nobody
+        # wrote must never hold a NaN pattern if a full-row kernel is switched in between two steps)
+        self.save_x = torch.zeros(B, lay.n_blocks + 1, L, lay.D, **f32)
+        self.save_h1 = torch.zeros(B, lay.n_blocks, L, lay.D, **f32)
+        self.save_aux = torch.zeros(_lib.lib().srfrd_aux_floats(C.byref(lay), B, L), **f32)
         self.loss_part = torch.empty(B, 3, **f32)
         self.loss = torch.zeros(1, **f32)
+        # Sequence -> workgroup schedule of the seq_len-50 ragged kernels (include/srfrd_hip.h, srfrd_seq_order): one small
+        # launch per step ranks the batch by length, forward and backward pair a long with a short sequence on every CU.
+        # SRFRD_SCHED = 0 (off: workgroup x takes sequence x) | 1 (static permutation) | 2 (dynamic, pairing by arrival; default)
+        self.sched_mode = int(os.environ.get("SRFRD_SCHED", "2")) if (L == 50 and lay.D == 50 and lay.n_heads == 1) else 0
+        self.sched = torch.zeros(int(_lib.lib().srfrd_sched_ints(B)), device=dev, dtype=torch.int32) if self.sched_mode else None
+        self.pair_stride = max(1, _lib.lib().srfrd_bwd_grid(C.byref(lay), 1 << 30, L) // 2)      # CUs: workgroups of the first round
         self.packed = model.pack_weights()
         check(_lib.lib().srfrd_step_begin(ptr(self.state), self.lr, self.betas[0], self.betas[1],
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "srfrd_step_begin")
@@ -148,10 +156,12 @@ class FusedTrainer:
                                     self.l2, ptr(self.l2_partial), ptr(self.l2buf), ptr(self.l2_dense), st), "srfrd_l2_norms")
         ids, fk, pfk, nfk, p, seed_dev, seq0 = self._ids_of(slot)
         lay_t, tab = self.model._table_args()
-        check(L_.srfrd_encoder_fwd(C.byref(lay_t), tab, self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
-                                   ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
-                                   ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), ptr(self.loss_part),
-                                   ptr(self.scratch), self.n_scratch, None, 0, st), "srfrd_encoder_fwd")
+        if self.sched_mode:
+            check(L_.srfrd_seq_order(ptr(ids[0]), self.B, self.L, self.pair_stride, ptr(self.sched), st), "srfrd_seq_order")
+        check(L_.srfrd_encoder_fwd_sched(C.byref(lay_t), tab, self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
+                                         ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
+                                         ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), ptr(self.loss_part),
+                                         ptr(self.scratch), self.n_scratch, ptr(self.sched), self.sched_mode, st), "srfrd_encoder_fwd_sched")
         if self.mode == "sharded":       # the statistics are forward outputs: reduce them now, exchange them under the backward
             check(L_.srfrd_loss_stats(ptr(self.loss_part), self.B, ptr(self.stats), None, st), "srfrd_loss_stats")
 
@@ -159,11 +169,11 @@ class FusedTrainer:
         L_, lay, st = _lib.lib(), self.lay, self._stream()
         ids, fk, pfk, nfk, p, seed_dev, seq0 = self._ids_of(slot)
         lay_t, tab = self.model._table_args()
-        check(L_.srfrd_encoder_bwd(C.byref(lay_t), tab, self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
-                                   ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
-                                   ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), None, None, None, 1,
-                                   ptr(self.grad), ptr(self.contrib), ptr(self.slabs), ptr(self.scratch), self.n_scratch, None, 0, st),
-              "srfrd_encoder_bwd")
+        check(L_.srfrd_encoder_bwd_sched(C.byref(lay_t), tab, self._dense_ptr(self.flat), ptr(self.packed), ptr(ids[0]), ptr(fk), ptr(ids[2]),
+                                         ptr(pfk), ptr(ids[4]), ptr(nfk), self.B, self.L, p, 0, seed_dev, seq0, ptr(self.hidden),
+                                         ptr(self.pl), ptr(self.nl), ptr(self.save_x), ptr(self.save_h1), ptr(self.save_aux), None, None, None, 1,
+                                         ptr(self.grad), ptr(self.contrib), ptr(self.slabs), ptr(self.scratch), self.n_scratch,
+                                         ptr(self.sched), self.sched_mode, st), "srfrd_encoder_bwd_sched")
         if self.contrib is not None:
             # deterministic item-table scatter: stable sort of the 3 B L row keys (pos, neg, input ids - the row order of
             # `contrib`), then one wave per item adds its rows in that order

@@ -71,7 +71,8 @@ def test_more_sequences_than_workgroups_at_c4_c5_lengths(kind, L):
     opt = O.Adam(sd_d)
     loss_fo, g_o = oracle_step_with_grads(cfg_d, sd_d, opt, full[1:], train=True, seed=O.step_seed(5, 1), b0=0)
     assert abs(float(loss_f.cpu()) - float(loss_fo)) < TOL
-    assert_post_adam(model_d.state_dict(), sd_d, [g_o], cfg_d.D)
+    # (2 M - 6 M ReLU units per step: a unit at its threshold may flip - tests/helpers.assert_post_adam, `outliers`)
+    assert_post_adam(model_d.state_dict(), sd_d, [g_o], cfg_d.D, outliers=2e-3)
 
 
 # ---- C4 at full size: 200 000 items, seq_len 100, 512 sequences per GPU (the per-GPU share of the 4096 global batch) ----

@@ -143,6 +143,8 @@ def main():
         replicas_equal = all(torch.equal(allp[0], g) for g in allp[1:])
         lay, D = model.layout, model.layout.D
         n_viol, worst, tight = 0, 0.0, []
+        where = {}
+        names = {id(p): n for n, p in model.named_parameters()}
         for i in range(K):
             d = (dp_post[i].double() - post_flat[i].double()).abs()
             tol = adam_tolerance([grads[i]]).to(d.device)
@@ -150,6 +152,10 @@ def main():
                 k0 = model.n_table_pad + lay.blk[b].in_b + D
                 tol[k0:k0 + D] = 1.0
             n_viol += int((d > tol).sum())
+            for p_, off in model._slots:          # (diagnostic: which tensors hold the violations)
+                c = int((d[off:off + p_.numel()] > tol[off:off + p_.numel()]).sum())
+                if c:
+                    where[f"step{i}:{names[id(p_)]}"] = c
             worst = max(worst, float(d.max()))
             tight.append(float((tol <= 1e-4).double().mean()))
         loss_diff = max(abs(a - b) for a, b in zip(dp_loss, ref_loss))
@@ -157,7 +163,7 @@ def main():
                   "steps": K, "global_batch": Bg, "seq_len": L, "dropout": 0.5, "dp_loss": dp_loss, "single_loss": ref_loss,
                   "max_loss_diff": loss_diff, "max_weight_diff": worst,
                   "weights_held_to_1e-4_or_tighter": min(tight), "weight_violations": n_viol,
-                  "replicas_bit_identical": bool(replicas_equal)}
+                  "replicas_bit_identical": bool(replicas_equal), "violations_in": where}
         ok = loss_diff < 1e-5 and n_viol == 0 and replicas_equal
         report["ok"] = bool(ok)
         print(json.dumps(report), flush=True)
