@@ -324,7 +324,7 @@ def main():
                        "global_batch": world * B, "seq_len": L, "n_items": cfg["n_items"],
                        "parallelism": f"dp{world}", "ranks": dist.get_world_size() if world > 1 else 1, "backend": "rccl" if backend == "nccl" else backend,
                        "exchange": tr.mode, "graph": not args.no_graph, "graph_form": tr.graph_form, "spin_up_replays": args.spin_up if not args.no_graph else 0,
-                       "valid_token_fraction": valid, "sequence_schedule": {0: "none", 1: "static length order", 2: "dynamic per-CU pairing"}[tr.sched_mode],
+                       "valid_token_fraction": valid, "sequence_schedule": {0: "none", 1: "length order (long + short sequence per CU)"}[tr.sched_mode],
                        "table_scatter": "sort + ordered sums" if args.deterministic else "float atomics",
                        "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,

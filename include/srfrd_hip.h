@@ -153,16 +153,16 @@ int srfrd_encoder_fwd(const srfrd_layout* lay, const void* item_table, const flo
  * Sequence -> workgroup schedule of the seq_len-50 ("ragged") encoder kernels.  At the reference's default geometry
  * (hidden 50, maxlen 50: trainer.py:123-129) srfrd_encoder_fwd / _bwd compute only the rows a left-padded sequence really
  * has, so a launch is as slow as its slowest CU - two workgroups share a CU, and a long sequence should share it with a
- * short one.  srfrd_seq_order ranks the batch's sequences by length (one small launch per batch: first non-pad position per
- * sequence, stable rank longest first, launch counters zeroed) into `sched` (int32[srfrd_sched_ints(B)], caller-owned,
- * valid for THIS batch only); the _sched forms of the encoder entry points take it:
+ * short one.  srfrd_seq_order (one small launch per batch) writes every sequence's first non-pad position into `sched`
+ * (int32[srfrd_sched_ints(B)], caller-owned, valid for THIS batch's input_ids only); the _sched forms of the encoder entry
+ * points take it:
  *   sched_mode 0  no schedule (== srfrd_encoder_fwd / _bwd: workgroup x takes sequences x, x + grid, ...)
- *   sched_mode 1  static: workgroup x takes the rank perm(x), perm = the `pair_stride` longest first, then the shortest
- *                 ascending (the workgroup that joins the longest sequence's CU brings the shortest), the rest descending
- *   sched_mode 2  dynamic: the first workgroup to ARRIVE on a CU takes the longest sequence left, the second the shortest
- *                 (backward: needs B <= srfrd_bwd_grid; falls back to mode 1 otherwise)
- * Results never depend on the schedule beyond the summation order of the dense-gradient slabs (static: per workgroup,
- * a function of the batch; dynamic: one slab per SEQUENCE).  Other geometries ignore the schedule.
+ *   sched_mode 1  length order: workgroup x takes the sequence of rank perm(x) (longest first, ties by index), perm = the
+ *                 `pair_stride` longest first, then the shortest ascending (the workgroup that joins the longest sequence's
+ *                 CU brings the shortest), the rest descending; every workgroup selects its sequence from the B lengths
+ *                 itself (no sort launch)
+ * Results never depend on the schedule beyond the summation order of the per-workgroup dense-gradient slabs, which is a
+ * function of the batch.  Other geometries ignore the schedule.
  * Reference counterpart: none (the reference runs stock torch ops over the full padded batch, SRFR_model.py:92-142).
  */
 int64_t srfrd_sched_ints(int B);
@@ -175,7 +175,7 @@ int srfrd_encoder_fwd_sched(const srfrd_layout* lay, const void* item_table, con
                             float* hidden, float* pos_logits, float* neg_logits,
                             float* save_x, float* save_h1, float* save_aux, float* loss_part,
                             float* scratch, int64_t scratch_floats,
-                            int32_t* sched, int sched_mode, void* stream);
+                            const int32_t* sched, int sched_mode, void* stream);
 int srfrd_encoder_bwd_sched(const srfrd_layout* lay, const void* item_table, const float* dense, const float* packed,
                             const int64_t* input_ids, const int64_t* fake_ids,
                             const int64_t* pos_ids, const int64_t* pos_fake,
@@ -186,7 +186,7 @@ int srfrd_encoder_bwd_sched(const srfrd_layout* lay, const void* item_table, con
                             const float* d_hidden, const float* d_pos, const float* d_neg, int fused_bce,
                             float* grad_table, float* table_contrib, float* grad_slabs,
                             float* scratch, int64_t scratch_floats,
-                            int32_t* sched, int sched_mode, void* stream);
+                            const int32_t* sched, int sched_mode, void* stream);
 
 /* Inference forward for ranking: the encoder state of the LAST position only, hidden_last (B, d_out) - what the reference's
  * predict() takes from log2feats (SRFR_model.py:668-681: `log_feats[:, -1, :]`).  Same arithmetic as srfrd_encoder_fwd in

@@ -43,22 +43,22 @@ struct EncArgs {
   float* dbg;
   int dbg_seq;
   int64_t dbg_slot;
-  // ragged kernels (seq_len 50): sequence -> workgroup schedule written by srfrd_seq_order (NULL: b = blockIdx.x, += gridDim.x)
-  int* sched;          // int32 workspace, layout below (kSched*)
-  int sched_mode;      // 0 none, 1 static (workgroup x takes the sorted list's entry perm(x)), 2 dynamic (per-CU pairing by arrival)
-  int sched_set;       // 0: forward's counters, 1: backward's
+  // ragged kernels (seq_len 50): sequence -> workgroup schedule from srfrd_seq_order's per-sequence lengths (NULL: b = blockIdx.x, += gridDim.x)
+  const int* sched;    // int32 workspace, layout below (kSched*)
+  int sched_mode;      // 0 none, 1 length order (workgroup x takes the sequence of rank perm(x): see rag_take)
+  int long_prio;       // ragged kernels: wave priority of sequences with three or four row tiles (0: none; experiment)
   int ragged_off;      // diagnostic: the ragged kernels compute every row (t0 = 0), as the full kernels do
 };
 
-// Schedule workspace (int32), filled by srfrd_seq_order for ONE batch; the counters of both launches are zeroed by it.
-//   [kSchedCnt + 16 set + {0 head, 1 tail, 2 taken}]   dynamic mode counters of launch `set` (0 forward, 1 backward)
-//   [kSchedTicket]                                     arrival ticket of srfrd_seq_order's own workgroups
-//   [kSchedG]                                          pair stride G of the static mode (workgroups per "first round": CUs)
-//   [kSchedArr + 2048 set + cu]                        workgroups arrived on hardware CU slot `cu` in launch `set`
-//   [kSchedLen + b]                                    first non-pad position t0 of sequence b
-//   [kSchedLen + B + i]                                sequence index of rank i, longest (fewest leading pads) first, ties by index
-constexpr int kSchedCnt = 0, kSchedTicket = 32, kSchedG = 33, kSchedArr = 64, kSchedLen = 64 + 2 * 2048;
-__host__ __device__ __forceinline__ int64_t sched_ints(int B) { return kSchedLen + 2ll * B; }
+// Schedule workspace (int32), filled by srfrd_seq_order for ONE batch:
+//   [kSchedG]        pair stride G (workgroups of the "first round": the CU count)
+//   [kSchedT0 + b]   first non-pad position t0 of sequence b (L: all padding)
+// The ragged kernels rank the sequences themselves (longest first = smallest t0 first, ties by index - a function of the
+// batch, so the summation order of the dense-gradient slabs is too): every workgroup selects the ONE sequence of the rank
+// it wants from the B lengths (a 64-bucket histogram in LDS + a ballot scan: rag_select) instead of a sort kernel ahead of
+// the launch - a one-workgroup sort costs more dependent memory round trips than it saves.
+constexpr int kSchedG = 0, kSchedT0 = 16;
+__host__ __device__ __forceinline__ int64_t sched_ints(int B) { return kSchedT0 + (int64_t)B; }
 
 // Checkpoint layout: SEQUENCE-major.  Everything the backward reads back for sequence b is contiguous per buffer -
 // save_x: (nb + 1) blocks of [L][D] at b * (nb + 1) * L * D; save_h1: nb blocks at b * nb * L * D; save_aux

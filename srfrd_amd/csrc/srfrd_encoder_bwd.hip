@@ -46,13 +46,13 @@ static int encoder_bwd_impl(const srfrd_layout* lay, const void* item_table, con
                             const float* save_x, const float* save_h1, const float* save_aux, const float* d_hidden,
                             const float* d_pos,
                             const float* d_neg, int fused_bce, float* grad_table, float* table_contrib, float* grad_slabs,
-                            float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq, int32_t* sched, int sched_mode,
+                            float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq, const int32_t* sched, int sched_mode,
                             void* stream) {
   EncArgs a = {};
   a.sched = sched_mode != 0 ? sched : nullptr;
   a.sched_mode = a.sched ? sched_mode : 0;
-  a.sched_set = 1;
   a.ragged_off = getenv("SRFRD_RAGGED_FULL_ROWS") != nullptr;
+  { const char* e = getenv("SRFRD_LONG_PRIO"); a.long_prio = e ? atoi(e) : 0; }
   int rc = fill_args(a, lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
                      dropout_p, seed, seed_dev, seq_index0);
   if (rc) return rc;
@@ -154,8 +154,8 @@ extern "C" int srfrd_encoder_bwd_sched(const srfrd_layout* lay, const void* item
                                        const float* save_x, const float* save_h1, const float* save_aux, const float* d_hidden,
                                        const float* d_pos, const float* d_neg, int fused_bce, float* grad_table,
                                        float* table_contrib, float* grad_slabs, float* scratch, int64_t scratch_floats,
-                                       int32_t* sched, int sched_mode, void* stream) {
-  if (sched_mode < 0 || sched_mode > 2 || (sched_mode != 0 && !sched)) return SRFRD_E_ARG;
+                                       const int32_t* sched, int sched_mode, void* stream) {
+  if (sched_mode < 0 || sched_mode > 1 || (sched_mode != 0 && !sched)) return SRFRD_E_ARG;
   return encoder_bwd_impl(lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L, dropout_p,
                           seed, seed_dev, seq_index0, hidden, pos_logits, neg_logits, save_x, save_h1, save_aux, d_hidden, d_pos,
                           d_neg, fused_bce, grad_table, table_contrib, grad_slabs, scratch, scratch_floats, nullptr, 0, sched,

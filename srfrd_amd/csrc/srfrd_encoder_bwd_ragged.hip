@@ -18,7 +18,6 @@ extern "C" int srfrd_bwd_ragged_launch(const void* args, int grid, int kind_vari
   const int64_t lds = bwd_ragged_lds_floats(a.dm.n_blocks) * 4;
   if (lds > kLdsLimit) return SRFRD_E_UNSUPPORTED;
   const bool rmw = a.B > grid;          // some workgroup takes a second sequence: its slab entries are read-modify-written
-  if (rmw && a.sched_mode == 2) a.sched_mode = 1;      // the dynamic schedule gives every SEQUENCE a slab: one sequence per workgroup only
 #define SRFRD_RB(K, DI) (rmw ? launch_enc(encoder_bwd_ragged_kernel<K, DI, true>, grid, 512, lds, stream, a) \
                              : launch_enc(encoder_bwd_ragged_kernel<K, DI, false>, grid, 512, lds, stream, a))
   switch (kind_variant) {

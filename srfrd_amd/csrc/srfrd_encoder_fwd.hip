@@ -106,13 +106,13 @@ static int encoder_fwd_impl(const srfrd_layout* lay, const void* item_table, con
                             double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
                             float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
                             float* save_aux, float* loss_part, float* scratch, int64_t scratch_floats, float* dbg, int dbg_seq,
-                            int last_only, int32_t* sched, int sched_mode, void* stream) {
+                            int last_only, const int32_t* sched, int sched_mode, void* stream) {
   EncArgs a = {};
   a.last_only = last_only;
   a.sched = sched_mode != 0 ? sched : nullptr;
   a.sched_mode = a.sched ? sched_mode : 0;
-  a.sched_set = 0;
   a.ragged_off = getenv("SRFRD_RAGGED_FULL_ROWS") != nullptr;
+  { const char* e = getenv("SRFRD_LONG_PRIO"); a.long_prio = e ? atoi(e) : 0; }
   int rc = fill_args(a, lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L,
                      dropout_p, seed, seed_dev, seq_index0);
   if (rc) return rc;
@@ -213,8 +213,8 @@ extern "C" int srfrd_encoder_fwd_sched(const srfrd_layout* lay, const void* item
                                        double dropout_p, uint32_t seed, const uint32_t* seed_dev, int64_t seq_index0,
                                        float* hidden, float* pos_logits, float* neg_logits, float* save_x, float* save_h1,
                                        float* save_aux, float* loss_part, float* scratch, int64_t scratch_floats,
-                                       int32_t* sched, int sched_mode, void* stream) {
-  if (sched_mode < 0 || sched_mode > 2 || (sched_mode != 0 && !sched)) return SRFRD_E_ARG;
+                                       const int32_t* sched, int sched_mode, void* stream) {
+  if (sched_mode < 0 || sched_mode > 1 || (sched_mode != 0 && !sched)) return SRFRD_E_ARG;
   return encoder_fwd_impl(lay, item_table, dense, packed, input_ids, fake_ids, pos_ids, pos_fake, neg_ids, neg_fake, B, L, dropout_p,
                           seed, seed_dev, seq_index0, hidden, pos_logits, neg_logits, save_x, save_h1, save_aux, loss_part, scratch,
                           scratch_floats, nullptr, 0, 0, sched, sched_mode, stream);

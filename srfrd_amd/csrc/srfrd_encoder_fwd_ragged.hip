@@ -1,7 +1,7 @@
 // Ragged fused encoder forward at the reference's default geometry (srfrd_encoder_fwd_ragged_kernel.inc): the forward of
 // reference SRFR_model.py:92-142 / :192-239 / :473-530 / :621-666 computed on the rows a left-padded sequence really has.
 // srfrd_encoder_fwd (srfrd_encoder_fwd.hip) dispatches here when shape and mode qualify.  Also home of srfrd_seq_order, the
-// per-batch length order both ragged kernels schedule their sequences by.
+// per-batch sequence lengths both ragged kernels schedule their sequences by.
 #include "srfrd_enc_common.h"
 
 #include "srfrd_encoder_fwd_ragged_kernel.inc"
@@ -10,63 +10,21 @@
 
 namespace srfrd {
 
-// ---- srfrd_seq_order: first non-pad position of every sequence, the sequences ranked longest first, counters zeroed ----
-// One wave per sequence reads its ids (coalesced) and ballots the first non-zero; the LAST workgroup to finish (arrival
-// ticket behind an agent-scope release) ranks the B lengths - rank = #{longer} + #{equally long with a smaller index}: a
-// stable order, so the schedule (and with it the summation order of the dense-gradient slabs) is a function of the batch.
-__global__ void __launch_bounds__(1024) seq_order_kernel(const int64_t* __restrict__ ids, int B, int L, int G, int* sched) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int* len = sched + kSchedLen;
-  for (int b = blockIdx.x * 16 + wave; b < B; b += gridDim.x * 16) {
-    int t0 = L;
-    for (int base = 0; base < L && t0 == L; base += 64) {
-      const int t = base + lane;
-      const bool nz = t < L && ids[(int64_t)b * L + t] != 0;
-      const unsigned long long m = __ballot(nz);
-      if (m) t0 = base + (int)__builtin_ctzll(m);
-    }
-    if (lane == 0) __hip_atomic_store(&len[b], t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- srfrd_seq_order: first non-pad position of every sequence (what the ragged kernels rank the batch by) ----
+// One wave per sequence reads its ids (coalesced) and ballots the first non-zero: one memory round trip, every CU in parallel.
+__global__ void __launch_bounds__(256) seq_order_kernel(const int64_t* __restrict__ ids, int B, int L, int G, int* sched) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) sched[kSchedG] = G;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  int t0 = L;
+  for (int base = 0; base < L && t0 == L; base += 64) {
+    const int t = base + lane;
+    const bool nz = t < L && ids[(int64_t)b * L + t] != 0;
+    const unsigned long long m = __ballot(nz);
+    if (m) t0 = base + (int)__builtin_ctzll(m);
   }
-  __shared__ int s_last;
-  __shared__ int s_len[4096];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int k = atomicAdd(&sched[kSchedTicket], 1);
-    s_last = k == (int)gridDim.x - 1;
-    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (!s_last) return;
-  int* sorted = sched + kSchedLen + B;
-  for (int c0 = 0; c0 < B; c0 += 4096) {       // (ranks against chunks of 4096 lengths held in LDS)
-    const int n = min(4096, B - c0);
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) s_len[i] = __hip_atomic_load(&len[c0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (c0 == 0 && B <= 4096) {
-      for (int b = tid; b < B; b += 1024) {
-        const int mine = s_len[b];
-        int rank = 0;
-        for (int j = 0; j < B; ++j) {
-          const int o = s_len[j];
-          rank += (o < mine || (o == mine && j < b)) ? 1 : 0;
-        }
-        sorted[rank] = b;
-      }
-    }
-  }
-  if (B > 4096)                                  // very large batches: identity order (the schedule only balances, never decides results)
-    for (int b = tid; b < B; b += 1024) sorted[b] = b;
-  for (int i = tid; i < 32; i += 1024) sched[kSchedCnt + i] = 0;
-  for (int i = tid; i < 2 * 2048; i += 1024) sched[kSchedArr + i] = 0;
-  if (tid == 0) {
-    sched[kSchedG] = G;
-    sched[kSchedTicket] = 0;
-  }
+  if (lane == 0) sched[kSchedT0 + b] = t0;
 }
 
 }  // namespace srfrd
@@ -77,9 +35,7 @@ extern "C" int64_t srfrd_sched_ints(int B) { return B > 0 ? sched_ints(B) : 0; }
 
 extern "C" int srfrd_seq_order(const int64_t* input_ids, int B, int L, int pair_stride, int32_t* sched, void* stream) {
   if (!input_ids || !sched || B <= 0 || L <= 0 || pair_stride <= 0) return SRFRD_E_ARG;
-  int grid = (B + 15) / 16;
-  if (grid > 64) grid = 64;
-  hipLaunchKernelGGL(seq_order_kernel, dim3(grid), dim3(1024), 0, (hipStream_t)stream, input_ids, B, L, pair_stride, sched);
+  hipLaunchKernelGGL(seq_order_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, input_ids, B, L, pair_stride, sched);
   return (int)hipGetLastError();
 }
 

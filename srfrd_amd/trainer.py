@@ -115,8 +115,8 @@ class FusedTrainer:
         self.loss = torch.zeros(1, **f32)
         # Sequence -> workgroup schedule of the seq_len-50 ragged kernels (include/srfrd_hip.h, srfrd_seq_order): one small
         # launch per step ranks the batch by length, forward and backward pair a long with a short sequence on every CU.
-        # SRFRD_SCHED = 0 (off: workgroup x takes sequence x) | 1 (static permutation) | 2 (dynamic, pairing by arrival; default)
-        self.sched_mode = int(os.environ.get("SRFRD_SCHED", "2")) if (L == 50 and lay.D == 50 and lay.n_heads == 1) else 0
+        # SRFRD_SCHED = 0 (off: workgroup x takes sequence x) | 1 (length order; default)
+        self.sched_mode = min(1, int(os.environ.get("SRFRD_SCHED", "1"))) if (L == 50 and lay.D == 50 and lay.n_heads == 1) else 0
         self.sched = torch.zeros(int(_lib.lib().srfrd_sched_ints(B)), device=dev, dtype=torch.int32) if self.sched_mode else None
         self.pair_stride = max(1, _lib.lib().srfrd_bwd_grid(C.byref(lay), 1 << 30, L) // 2)      # CUs: workgroups of the first round
         self.packed = model.pack_weights()
