@@ -14,7 +14,10 @@ using namespace srfrd;
 extern "C" int srfrd_bwd_ragged_launch(const void* args, int grid, int kind_variant, void* stream) {
   EncArgs a;
   std::memcpy(&a, args, sizeof(a));
-  if (a.dm.D != 50 || a.L != 50 || a.dm.n_heads != 1 || a.dm.n_blocks > SRFRD_MAX_BLOCKS || a.dbg) return SRFRD_E_UNSUPPORTED;
+  if (a.dm.D != 50 || a.L != 50 || a.dm.n_heads != 1 || a.dm.n_blocks > SRFRD_MAX_BLOCKS ) return SRFRD_E_UNSUPPORTED;
+#ifndef SRFRD_STAMPS
+  if (a.dbg) return SRFRD_E_UNSUPPORTED;       // debug taps want every row of every intermediate: the full kernels
+#endif
   const int64_t lds = bwd_ragged_lds_floats(a.dm.n_blocks) * 4;
   if (lds > kLdsLimit) return SRFRD_E_UNSUPPORTED;
   const bool rmw = a.B > grid;          // some workgroup takes a second sequence: its slab entries are read-modify-written

@@ -157,7 +157,12 @@ static int encoder_fwd_impl(const srfrd_layout* lay, const void* item_table, con
   // The reference's default geometry: the ragged kernel (rows of the left-padded sequence only).  A forward that writes
   // training checkpoints takes it exactly when the backward of this (layout, length) will be the ragged one (ragged_pair);
   // debug taps want every row of every intermediate: the full kernel.
-  if (!dbg && ragged_pair(lay, L)) {
+#ifdef SRFRD_STAMPS
+  const bool taps_f = false;                   // (diagnostic build: `dbg` receives the phase stamps)
+#else
+  const bool taps_f = dbg != nullptr;
+#endif
+  if (!taps_f && ragged_pair(lay, L)) {
     const bool train = pos_ids && neg_ids && save_x && loss_part && dropout_p > 0.0 && getenv("SRFRD_NO_TSPEC") == nullptr;
     rc = srfrd_fwd_ragged_launch(&a, ragged_variant(lay), train ? 1 : 0, grid, stream);
     if (rc != SRFRD_E_UNSUPPORTED) return rc;

@@ -44,7 +44,10 @@ extern "C" int srfrd_seq_order(const int64_t* input_ids, int B, int L, int pair_
 extern "C" int srfrd_fwd_ragged_launch(const void* args, int kind_variant, int train, int grid, void* stream) {
   EncArgs a;
   std::memcpy(&a, args, sizeof(a));
-  if (a.dm.D != 50 || a.L != 50 || a.dm.n_heads != 1 || a.dm.n_blocks > SRFRD_MAX_BLOCKS || a.dbg) return SRFRD_E_UNSUPPORTED;
+  if (a.dm.D != 50 || a.L != 50 || a.dm.n_heads != 1 || a.dm.n_blocks > SRFRD_MAX_BLOCKS ) return SRFRD_E_UNSUPPORTED;
+#ifndef SRFRD_STAMPS
+  if (a.dbg) return SRFRD_E_UNSUPPORTED;       // debug taps want every row of every intermediate: the full kernels
+#endif
   const Geom g = make_geom(50, 50);
   const int64_t lds = fwd_lds_floats(g, a.dm.n_blocks) * 4;
   if (lds > kLdsLimit) return SRFRD_E_UNSUPPORTED;

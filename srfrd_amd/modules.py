@@ -79,6 +79,45 @@ class SRFU_Embedding(nn.Module):
         return self.user_label_embed
 
 
+class _EncoderFn(torch.autograd.Function):
+    """forward() of the drop-in modules under autograd: the same two launches as the registered ``srfrd::encoder_fwd`` /
+    ``srfrd::encoder_bwd`` custom ops (srfrd_amd/ops.py - dispatcher-visible, opcheck'ed, and what ``module.library_ops =
+    True`` routes through), without the Python glue torch.library generates around a custom op's autograd (measured: ~300 us
+    of host time per training step at C2, more than the kernels take).  Unused outputs hand back None instead of a zero
+    tensor (``set_materialize_grads(False)``): the backward then knows no hidden-state gradient exists and its head runs
+    over the sequence's own rows only."""
+
+    @staticmethod
+    def forward(ctx, model, p, seed, inp, fk, pos, pfk, neg, nfk, *params):
+        out = model._launch_fwd(inp, fk, pos, pfk, neg, nfk, p, seed, True)
+        ctx.model, ctx.meta = model, (p, seed)
+        ctx.id_present = tuple(t is not None for t in (inp, fk, pos, pfk, neg, nfk))
+        ctx.have = (pos is not None, neg is not None)
+        ctx.set_materialize_grads(False)
+        hidden = out["hidden"]
+        pl = out["pos_logits"] if pos is not None else hidden.new_empty(0)
+        nl = out["neg_logits"] if neg is not None else hidden.new_empty(0)
+        ctx.save_for_backward(hidden, pl, nl, out["save_x"], out["save_h1"], out["save_aux"],
+                              *[t for t in (inp, fk, pos, pfk, neg, nfk) if t is not None])
+        return hidden, pl, nl
+
+    @staticmethod
+    def backward(ctx, d_hidden, d_pl, d_nl):
+        m = ctx.model
+        p, seed = ctx.meta
+        saved = ctx.saved_tensors
+        hidden, pl, nl, sx, sh, sa = saved[:6]
+        rest = iter(saved[6:])
+        inp, fk, pos, pfk, neg, nfk = (next(rest) if present else None for present in ctx.id_present)
+        out = {"hidden": hidden, "pos_logits": pl if ctx.have[0] else None, "neg_logits": nl if ctx.have[1] else None,
+               "save_x": sx, "save_h1": sh, "save_aux": sa}
+        gflat = m._launch_bwd(inp, fk, pos, pfk, neg, nfk, p, seed, out,
+                              None if d_hidden is None else d_hidden.contiguous(),
+                              None if (d_pl is None or pos is None) else d_pl.contiguous(),
+                              None if (d_nl is None or neg is None) else d_nl.contiguous())
+        return (None,) * 9 + m._grad_views(gflat)
+
+
 class _SRFRDBase(nn.Module):
     """Shared machinery: flat parameter storage, kernel launches, predict."""
 
@@ -349,12 +388,46 @@ class _SRFRDBase(nn.Module):
         exactly as in the reference (SRFR_model.py:92, :192, :473, :651)."""
         ids = self._prep(input_ids, fake_ids, positive_ids, positive_fake_ids, negative_ids, negative_fake_ids)
         p = self.dropout_rate if self.training else 0.0
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
-        # torch.ops.srfrd.encoder_fwd (srfrd_amd/ops.py): the parameters are op inputs, its registered backward runs
-        # srfrd::encoder_bwd and hands one gradient per parameter to autograd
+        seed = self._next_seed() if p > 0 else 0
         grad = torch.is_grad_enabled() and any(q.requires_grad for q, _ in self._slots)
-        hidden, pl, nl, *_ = torch.ops.srfrd.encoder_fwd([q for q, _ in self._slots], *ids, ops.register_model(self), p, seed, 0, grad)
+        if getattr(self, "library_ops", False):
+            # torch.ops.srfrd.encoder_fwd (srfrd_amd/ops.py): the parameters are op inputs, its registered backward runs
+            # srfrd::encoder_bwd and hands one gradient per parameter to autograd
+            hidden, pl, nl, *_ = torch.ops.srfrd.encoder_fwd([q for q, _ in self._slots], *ids, ops.register_model(self), p, seed, 0, grad)
+        elif grad:
+            hidden, pl, nl = _EncoderFn.apply(self, p, seed, *ids, *[q for q, _ in self._slots])
+        else:
+            out = self._launch_fwd(*ids, p, seed, False)
+            hidden, pl, nl = out["hidden"], out["pos_logits"], out["neg_logits"]
         return hidden, (pl if ids[2] is not None else None), (nl if ids[4] is not None else None)
+
+    def _next_seed(self):
+        """dropout seed of one forward: a host-side counter hashed with torch's seed (torch.manual_seed reproduces a run; no
+        device random number, no host sync - the reference's nn.Dropout draws on the device stream without either)"""
+        base = torch.initial_seed() & 0xFFFFFFFF
+        if getattr(self, "_seed_base", None) != base:
+            self._seed_base, self._seed_ctr = base, 0
+        self._seed_ctr += 1
+        h = (base * 0x9E3779B1 + self._seed_ctr * 0x85EBCA6B) & 0xFFFFFFFF
+        h ^= h >> 15
+        return (h * 0x2C1B3C6D) & 0x7FFFFFFF
+
+    def _grad_views(self, gflat):
+        """one gradient view per parameter (order of _slots) of the flat gradient vector: a single split + reshapes"""
+        if getattr(self, "_split_sizes", None) is None or self._split_n != gflat.numel():
+            if any(b[1] < a[1] + a[0].numel() for a, b in zip(self._slots, self._slots[1:])):      # (never: the layout is ascending)
+                return tuple(gflat[off:off + q.numel()].view(q.shape) for q, off in self._slots)
+            sizes, keep, at = [], [], 0
+            for q, off in self._slots:
+                if off > at:
+                    sizes.append(off - at); keep.append(False)
+                sizes.append(q.numel()); keep.append(True)
+                at = off + q.numel()
+            if at < gflat.numel():
+                sizes.append(gflat.numel() - at); keep.append(False)
+            self._split_sizes, self._split_keep, self._split_n = sizes, keep, gflat.numel()
+        parts = gflat.split_with_sizes(self._split_sizes)
+        return tuple(t.view(q.shape) for (t, k), (q, _) in zip(((t, k) for t, k in zip(parts, self._split_keep) if k), self._slots))
 
     def user_labels(self, fake_ids):
         """get_Labels (SRFU_*) / the predict-time label (SRFRN) as an int64 (B,) tensor, computed on device."""

@@ -123,7 +123,7 @@ def _fwd_backward(ctx, grads):
                                         None if d_hidden is None else d_hidden.contiguous(),
                                         None if (d_pl is None or pos is None) else d_pl.contiguous(),
                                         None if (d_nl is None or neg is None) else d_nl.contiguous())
-    per_param = [gflat[off:off + q.numel()].view(q.shape) for q, off in m._slots]
+    per_param = list(m._grad_views(gflat))
     assert len(per_param) == n_params
     return (per_param,) + (None,) * 11
 

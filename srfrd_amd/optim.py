@@ -29,6 +29,7 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("srfrd_amd.Adam takes ONE parameter group: model.parameters() of one srfrd_amd module")
         self._flat = self._m = self._v = self._gbuf = self._dev_state = None
         self._spans = None
+        self._p0 = self._pl = None
         self._steps = 0
 
     # ---- the flat vector behind the parameters -------------------------------------------------------------------------
@@ -94,9 +95,9 @@ class Adam(torch.optim.Optimizer):
             return loss
         if ps[0].device.type != "cuda":
             raise RuntimeError("srfrd_amd.Adam runs on the ROCm GPU only (no CPU fallback)")
-        if self._spans is None or any(p.storage_offset() != off or p.untyped_storage().data_ptr() != self._flat.untyped_storage().data_ptr()
-                                      for p, off, _ in self._spans):
-            self._resolve()
+        if self._spans is None or ps[0].data_ptr() != self._p0 or ps[-1].data_ptr() != self._pl:
+            self._resolve()             # (first step, or the model re-flattened its parameters)
+            self._p0, self._pl = ps[0].data_ptr(), ps[-1].data_ptr()
         g = self.param_groups[0]
         lr, (b1, b2), eps = g["lr"], g["betas"], g["eps"]
         gptr, keep = self._flat_grad()

@@ -483,3 +483,29 @@ def test_spin_up_leaves_the_training_trajectory_untouched():
     for i in s0:
         for name in ("exp_avg", "exp_avg_sq"):
             assert torch.equal(s0[i][name], s1[i][name]), (i, name)
+
+
+@pytest.mark.parametrize("kind", ["SASRec", "SRFRN"])
+def test_module_forward_paths_agree(kind):
+    """forward() under autograd runs the launchers through a light torch.autograd.Function; ``library_ops = True`` routes the
+    same call through the registered srfrd::encoder_fwd custom op (srfrd_amd/ops.py): same outputs, same gradients."""
+    import copy
+    import srfrd_amd
+    from tests.gpu_util import build_model, cuda, random_sd
+    cfg = _cfg50(kind)
+    sd = random_sd(cfg, 41)
+    m1 = build_model(cfg, sd).train()
+    m2 = copy.deepcopy(m1)
+    m2.library_ops = True
+    batch = cuda(*srfrd_amd.synthetic_batch(400, 50, 12, seed=8, device="cpu")[1:])
+    outs = []
+    for m in (m1, m2):
+        h, pl, nl = m(None, *batch)
+        _loss(pl, nl, batch[2]).backward()
+        outs.append((h, pl, nl))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # (the registered op materialises a zero hidden-state gradient, so its backward's head walks every row; the Function
+    # path passes None and the head starts at the first item: the same sums in another order)
+    for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert float((p.grad - q.grad).abs().max()) < 1e-6, k

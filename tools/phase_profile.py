@@ -23,7 +23,7 @@ def build():
     os.makedirs(tmp + "/include", exist_ok=True)
     for f in os.listdir(CSRC):
         open(f"{tmp}/srfrd_amd/csrc/{f}", "w").write(open(os.path.join(CSRC, f)).read())
-    for which in ("fwd", "bwd", "bwd_slots", "bwd_chunks"):
+    for which in ("fwd", "bwd", "bwd_slots", "bwd_chunks", "fwd_ragged", "bwd_ragged"):
         fname = f"srfrd_encoder_{which}_kernel.inc"
         out = _stamp_file(os.path.join(CSRC, fname), which, labels)
         open(f"{tmp}/srfrd_amd/csrc/{fname}", "w").write("\n".join(out))
@@ -86,6 +86,7 @@ def run():
     m = m.cuda().train()
     _, seq, rsq, pos, prs, neg, nrs = srfrd_amd.synthetic_batch(I, L, B, seed=1, device="cuda")
     ids = m._prep(seq, None, pos, None, neg, None)
+    ragged = os.environ.get("SRFRD_NO_RAGGED") is None
     for which in ("fwd", "bwd"):
         dbg = torch.zeros(1024, 128, device="cuda", dtype=torch.int64)
         dbg2 = torch.zeros(1024, 128, device="cuda", dtype=torch.int64)
@@ -110,9 +111,15 @@ def run():
         mean = used.mean(0)
         tot = float(mean.sum())
         print(f"== {which}: {used.shape[0]} workgroups, {tot:.0f} ticks (100 MHz -> {tot / 100:.1f} us) per workgroup")
+        # the slowest tenth of the workgroups (the long sequences: a launch lasts as long as they do)
+        tot_wg = used.sum(1)
+        slow = used[tot_wg >= tot_wg.quantile(0.9)].mean(0)
+        fast = used[tot_wg <= tot_wg.quantile(0.3)].mean(0)
+        print(f"   slowest 10 %: {float(slow.sum()):.0f} ticks; fastest 30 %: {float(fast.sum()):.0f} ticks")
+        lab = which + ("_ragged" if ragged else "")
         for i in range(128):
             if mean[i] > 0:
-                print(f"  {i:3d} {float(mean[i]):9.0f} {100 * float(mean[i]) / tot:5.1f}%  {labels.get(f'{which}:{i}', '')}")
+                print(f"  {i:3d} {float(mean[i]):9.0f} {100 * float(mean[i]) / tot:5.1f}%  slow {float(slow[i]):8.0f} fast {float(fast[i]):8.0f}  {labels.get(f'{lab}:{i}', labels.get(f'{which}:{i}', ''))}")
 
 
 def run_c4(I=200_000, L=100, which="bwd_slots"):
