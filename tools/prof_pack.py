@@ -37,10 +37,10 @@ def main():
             rows = list(c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
             with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
                 w = csv.writer(f)
-                w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+                w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
                 w.writerows(rows)
             for r in rows[:8]:
-                print(f"{r[0][:80]:80s} {r[1]:6d} {r[3] / 1e3:9.2f} us")
+                print(f"{r[0][:80]:80s} {r[1]:6d} {r[3]:9.2f} us")
         else:
             name = key.split(":", 1)[1]
             per = {}
