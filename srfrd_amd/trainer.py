@@ -42,8 +42,14 @@ class FusedTrainer:
 
     def __init__(self, model, batch_size: int, seq_len: int | None = None, lr: float = 1e-3, betas=(0.9, 0.98),
                  eps: float = 1e-8, l2_emb: float = 0.0, seed: int = 42, process_group=None, use_graph: bool = True,
-                 slots: int = 1, exchange: str = "sharded", deterministic: bool = False):
-        """``deterministic``: the item-table gradient is scattered by a stable sort + per-item ordered sums instead of float
+                 slots: int = 1, exchange: str = "sharded", deterministic: bool = False, shadow_gather: bool = False):
+        """``shadow_gather`` (sharded exchange over a bf16 item-table shadow, ``model.use_bf16_table()``; SURVEY 8e's alternative
+        for BASELINE configs[4]): the fp32 master of an item row and its Adam moments live on the OWNER rank only; after the
+        sharded Adam step the all-gather carries the bf16 SHADOW of the table (2 bytes per element: 90 MB instead of 180 MB at
+        1 M items) and a small all-reduce the dense parameters.  Every gather of the step reads the shadow, so the arithmetic
+        is that of the bf16-table mode; a rank's fp32 rows OUTSIDE its shard go stale - call ``sync_master()`` (one fp32
+        all-gather) before reading ``model.state_dict()`` / saving a checkpoint.
+        ``deterministic``: the item-table gradient is scattered by a stable sort + per-item ordered sums instead of float
         atomics - every step bitwise reproducible (the dense gradients already are: fixed slab tree), at the cost of one
         sort of 3 B L keys per step."""
         self.model = model
@@ -63,6 +69,9 @@ class FusedTrainer:
         if exchange not in ("sharded", "allreduce"):
             raise ValueError("exchange must be 'sharded' or 'allreduce'")
         self.mode = exchange if self.ex.on else "single"      # (ex.on: world > 1, or a forced exchange in a group of one)
+        self.shadow_gather = bool(shadow_gather) and self.mode == "sharded"
+        if shadow_gather and self.mode == "sharded" and not model.bf16_table:
+            raise ValueError("shadow_gather exchanges the bf16 item-table shadow: call model.use_bf16_table() first")
         lay, B, L = self.lay, self.B, self.L
         f32 = dict(device=dev, dtype=torch.float32)
         if self.mode == "sharded":
@@ -75,6 +84,15 @@ class FusedTrainer:
             self.recv = torch.zeros(self.ex.per, **f32)
             self.m = torch.zeros(self.ex.per, **f32)
             self.v = torch.zeros(self.ex.per, **f32)
+            if self.shadow_gather:
+                # the shadow padded to the shard grid (the all-gather walks the flat index space in 2-byte elements); the
+                # model's kernels keep reading its first n_table elements
+                self.shadow_pad = torch.zeros(self.ex.n_pad, device=dev, dtype=torch.int16)
+                self.shadow_pad[:self.lay.n_table].copy_(model._table16)
+                model._table16 = self.shadow_pad[:self.lay.n_table]
+                model._bf16_auto = False                     # (the trainer keeps the shadow current; the fp32 table is partly stale)
+                self.n_dense_x = self.n_flat - self.n_tab    # dense parameters (+ tail padding): exchanged in fp32
+                self.dense_x = torch.zeros(self.n_dense_x, **f32)
         else:
             self.grad = torch.zeros(self.n_flat + 4, **f32)      # [table | dense | stats(4)]: one vector, one all-reduce
             self.stats = self.grad[self.n_flat:]
@@ -215,16 +233,40 @@ class FusedTrainer:
         bias = 4 * ex.i0
         if self.l2 != 0.0:
             self._enqueue_l2_apply(C.c_void_p(self.recv.data_ptr() - bias), self.flat_pad, ex.i0, ex.i1)
+        sg = self.shadow_gather      # (the owner writes the bf16 shadow of the table elements it steps)
         check(L_.srfrd_adam_step(ptr(self.flat_pad), C.c_void_p(self.recv.data_ptr() - bias), C.c_void_p(self.m.data_ptr() - bias),
                                  C.c_void_p(self.v.data_ptr() - bias), ex.n_pad, ex.i0, ex.i1, 0, self.betas[0], self.betas[1],
-                                 self.eps, ptr(self.state), ptr(self.stats), None, 0, st), "srfrd_adam_step")
+                                 self.eps, ptr(self.state), ptr(self.stats), ptr(self.shadow_pad) if sg else None,
+                                 self.lay.n_table if sg else 0, st), "srfrd_adam_step")
+        if sg:
+            # this rank's part of the dense parameters into the exchange buffer (zeros elsewhere: the SUM all-reduce is a gather)
+            self.dense_x.zero_()
+            lo, hi = max(ex.i0, self.n_tab), min(ex.i1, self.n_flat)
+            if hi > lo:
+                self.dense_x[lo - self.n_tab:hi - self.n_tab].copy_(self.flat_pad[lo:hi])
+
+    def _gather_params(self):
+        """sharded form: every rank's stepped slice to all ranks - the fp32 vector, or (shadow_gather) the bf16 shadow of the
+        table + the dense parameters"""
+        if not self.shadow_gather:
+            self.ex.all_gather(self.flat_pad)
+            return
+        self.ex.all_gather(self.shadow_pad.view(torch.float16))      # (2-byte elements; RCCL has no int16: the bits travel as fp16)
+        self.ex.all_reduce(self.dense_x)
+        self.flat[self.n_tab:self.n_flat].copy_(self.dense_x)
+
+    def sync_master(self):
+        """shadow_gather: bring every rank's fp32 parameters up to date (one fp32 all-gather; a collective - every rank calls
+        it).  No-op otherwise."""
+        if self.shadow_gather:
+            self.ex.all_gather(self.flat_pad)
 
     def _enqueue_shard_finish(self):
         """sharded form, after the all-gather: fragment-ordered copy of the stepped weights + optimizer-state advance + loss"""
         L_, st = _lib.lib(), self._stream()
         check(L_.srfrd_pack_weights(C.byref(self.lay), self._dense_ptr(self.flat), ptr(self.packed), ptr(self.state), self.lr,
                                     self.betas[0], self.betas[1], st), "srfrd_pack_weights")
-        if self.model._table16 is not None:      # bf16 shadow of the all-gathered item table (every rank needs all rows)
+        if self.model._table16 is not None and not self.shadow_gather:      # bf16 shadow of the all-gathered item table (every rank needs all rows)
             check(L_.srfrd_table_to_bf16(ptr(self.flat), self.lay.n_table, ptr(self.model._table16), st), "srfrd_table_to_bf16")
         check(L_.srfrd_loss_finalize(ptr(self.stats), ptr(self.loss), st), "srfrd_loss_finalize")
         if self.l2 != 0.0:
@@ -244,13 +286,13 @@ class FusedTrainer:
             if h is not None:
                 h.wait()
             self._enqueue_shard_update()
-            self.ex.all_gather(self.flat_pad)
+            self._gather_params()
             self._enqueue_shard_finish()
 
     def _capture(self):
         # warm-up on a side stream (sets the LDS attributes, loads code objects), then capture
         torch.cuda.synchronize()
-        keep = [self.flat, self.m, self.v, self.state, self.grad, self.stats]
+        keep = [self.flat, self.m, self.v, self.state, self.grad, self.stats] + ([self.shadow_pad] if self.shadow_gather else [])
         snap = [t.clone() for t in keep]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -268,7 +310,8 @@ class FusedTrainer:
             for dst, src in zip(keep, snap):
                 dst.copy_(src)
             self.model.pack_weights()         # the warm-up step re-packed the stepped weights: restore that too
-            self.model.refresh_bf16_table()   # ... and re-derived the bf16 shadow of the stepped table (if one is in use)
+            if not self.shadow_gather:        # ... and re-derived the bf16 shadow of the stepped table (if one is in use;
+                self.model.refresh_bf16_table()   # shadow_gather: the shadow itself is part of the snapshot)
 
         restore()
         # thread_local capture mode: a collective backend's watchdog thread may touch the HIP runtime while we capture
@@ -337,7 +380,7 @@ class FusedTrainer:
         if self._graph_a is None and self._graph_one is None:
             self._capture()
         torch.cuda.synchronize()
-        keep = [self.flat, self.m, self.v, self.state, self.grad, self.stats]
+        keep = [self.flat, self.m, self.v, self.state, self.grad, self.stats] + ([self.shadow_pad] if self.shadow_gather else [])
         snap = [t.clone() for t in keep]
         if self._graph_one is not None:      # (collectives inside: every rank replays the same number of times)
             seq = [self._graph_one[0]]
@@ -351,7 +394,8 @@ class FusedTrainer:
         for dst, src in zip(keep, snap):
             dst.copy_(src)
         self.model.pack_weights()
-        self.model.refresh_bf16_table()
+        if not self.shadow_gather:
+            self.model.refresh_bf16_table()
         torch.cuda.synchronize()
 
     def refresh(self):
@@ -501,7 +545,7 @@ class FusedTrainer:
             if h is not None:
                 h.wait()
             self._graph_u.replay()
-            self.ex.all_gather(self.flat_pad)
+            self._gather_params()
             self._graph_b.replay()
         self.steps_done += 1
         return self.loss

@@ -69,3 +69,18 @@ def test_three_ranks_srfrn_sharded():
     """uneven shard edges (n_flat is not a multiple of 3 x 4) and the [item || fake] kind"""
     rep = run_dp_parity("--exchange", "sharded", "--kind", "SRFRN", "--batch", "24", nproc=3)
     assert rep["world"] == 3 and rep["ok"]
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_two_ranks_shadow_gather(graph):
+    """BASELINE configs[4]'s data-parallel form: fp32 master + Adam moments on the owner rank only, the all-gather
+    carries the bf16 shadow of the item table (half the bytes), a small all-reduce the dense parameters; every step equals
+    the single-rank bf16-table step, the gathered shadow equals bf16(master) bit for bit on every rank."""
+    rep = run_dp_parity("--exchange", "sharded", "--shadow-gather", *([] if graph else ["--eager"]))
+    assert rep["world"] == 2 and rep["shadow_gather"] and rep["ok"]
+    assert rep["max_loss_diff"] < 1e-5 and rep["weight_violations"] == 0 and rep["replicas_bit_identical"]
+
+
+def test_three_ranks_shadow_gather_srfrn():
+    rep = run_dp_parity("--exchange", "sharded", "--shadow-gather", "--kind", "SRFRN", "--batch", "24", nproc=3)
+    assert rep["world"] == 3 and rep["shadow_gather"] and rep["ok"]

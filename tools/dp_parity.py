@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=50)
     ap.add_argument("--l2-emb", type=float, default=0.0, help="reference trainer.py:39 with a non-zero config.l2_emb")
     ap.add_argument("--spin-up", action="store_true", help="call FusedTrainer.spin_up() before every step (must change nothing)")
+    ap.add_argument("--shadow-gather", action="store_true", help="bf16 item-table shadow; the all-gather carries the shadow, fp32 "
+                    "master rows live on the owner rank only (FusedTrainer(shadow_gather=True)); the reference is the single-rank "
+                    "bf16-table step")
     args = ap.parse_args()
     world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -81,7 +84,10 @@ def main():
         for _, p in m.named_parameters():
             if p.dim() >= 2:
                 torch.nn.init.xavier_normal_(p.data)
-        return m.to(dev).train()
+        m = m.to(dev).train()
+        if args.shadow_gather:
+            m.use_bf16_table()
+        return m
 
     batches = [srfrd_amd.synthetic_batch(I, L, Bg, seed=5, index=i, device=dev, packed=True)[1] for i in range(args.steps)]
     model = make_model()
@@ -114,7 +120,9 @@ def main():
             dist.broadcast(c, src=0)
             t.copy_(c)
     # ---- the data-parallel trainer, every step from the recorded state
-    tr = srfrd_amd.FusedTrainer(model, Bl, L, seed=17, use_graph=not args.eager, exchange=args.exchange, l2_emb=args.l2_emb)
+    tr = srfrd_amd.FusedTrainer(model, Bl, L, seed=17, use_graph=not args.eager, exchange=args.exchange, l2_emb=args.l2_emb,
+                                shadow_gather=args.shadow_gather)
+    assert tr.shadow_gather == (args.shadow_gather and args.exchange == "sharded")
     assert tr.world == world and tr.mode == args.exchange
     dp_loss, dp_post = [], []
     for i in range(K):
@@ -128,9 +136,16 @@ def main():
             tr.m.copy_(pre_m[i]); tr.v.copy_(pre_v[i])
         tr.state.copy_(pre_state[i])
         tr.refresh()
+        model.refresh_bf16_table()                 # (the recorded fp32 state is complete on every rank: derive the shadow from it)
         if args.spin_up:
             tr.spin_up(3)
         dp_loss.append(float(tr.step_packed(batches[i][:, rank * Bl:(rank + 1) * Bl].contiguous()).cpu()))
+        if tr.shadow_gather:
+            # the gathers of the NEXT step would read this shadow: it must equal bf16(master) for every row, on every rank
+            shadow_now = model._table16.clone()
+            tr.sync_master()                       # (fp32 rows outside the own shard are stale until asked for)
+            want = model.flat_parameters()[:model.layout.n_table].to(torch.bfloat16).view(torch.int16)
+            assert torch.equal(shadow_now, want), "gathered bf16 shadow != bf16(all-gathered fp32 master)"
         dp_post.append(model.flat_parameters().detach().clone())
     tr.check()
     # replicas identical?
@@ -163,7 +178,7 @@ def main():
                   "steps": K, "global_batch": Bg, "seq_len": L, "dropout": 0.5, "dp_loss": dp_loss, "single_loss": ref_loss,
                   "max_loss_diff": loss_diff, "max_weight_diff": worst,
                   "weights_held_to_1e-4_or_tighter": min(tight), "weight_violations": n_viol,
-                  "replicas_bit_identical": bool(replicas_equal), "violations_in": where}
+                  "replicas_bit_identical": bool(replicas_equal), "violations_in": where, "shadow_gather": bool(tr.shadow_gather)}
         ok = loss_diff < 1e-5 and n_viol == 0 and replicas_equal
         report["ok"] = bool(ok)
         print(json.dumps(report), flush=True)

@@ -74,6 +74,23 @@ def main():
                                                "weights_bit_equal": bool(torch.equal(flat, ref_flat))}
     report["ok"] = report["ok"] and tr.graph_form == "split" and losses == ref_loss and bool(torch.equal(flat, ref_flat))
     os.environ.pop("SRFRD_DP_SPLIT_GRAPHS")
+    # shadow_gather (SURVEY 8e for BASELINE configs[4]): bf16 item-table shadow all-gathered instead of the fp32 vector
+    def run_bf16(forced, shadow):
+        os.environ["SRFRD_FORCE_EXCHANGE"] = "1" if forced else "0"
+        m = make_model()
+        m.use_bf16_table()
+        tr = srfrd_amd.FusedTrainer(m, B, L, seed=17, use_graph=True, exchange="sharded", deterministic=True, shadow_gather=shadow)
+        losses = [float(tr.step_packed(batches[i]).cpu()) for i in range(K)]
+        tr.sync_master()
+        torch.cuda.synchronize()
+        return tr, losses, tr.flat[:m.n_flat].detach().clone(), m._table16.clone()
+
+    _, l0, f0, s0 = run_bf16(False, False)
+    tr, l1, f1, s1 = run_bf16(True, True)
+    ok = tr.shadow_gather and l0 == l1 and bool(torch.equal(f0, f1)) and bool(torch.equal(s0, s1))
+    report["forms"]["sharded/shadow_gather"] = {"graph_form": tr.graph_form, "loss_bit_equal": l0 == l1,
+                                                "weights_bit_equal": bool(torch.equal(f0, f1)), "shadow_bit_equal": bool(torch.equal(s0, s1))}
+    report["ok"] = report["ok"] and ok
     # row-sharded ranking: the nccl arm of ranker._all_gather (one shard = the whole catalog at world 1)
     os.environ["SRFRD_FORCE_EXCHANGE"] = "1"
     for kind in ("SASRec", "SRFRN"):
