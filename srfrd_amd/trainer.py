@@ -297,12 +297,17 @@ class FusedTrainer:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._enqueue_compute()
-            if self.mode == "sharded":
-                self._enqueue_shard_update()
-                self._enqueue_shard_finish()
+            if self.mode != "single" and self.ex.native:
+                # RCCL: one whole step EAGERLY, collectives included, before anything is captured - every collective type the
+                # graph will hold has then run once on this communicator (lazy channel / buffer set-up cannot be captured)
+                self._enqueue_dp_step()
             else:
-                self._enqueue_update()
+                self._enqueue_compute()
+                if self.mode == "sharded":
+                    self._enqueue_shard_update()
+                    self._enqueue_shard_finish()
+                else:
+                    self._enqueue_update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
 
