@@ -63,8 +63,10 @@ class ShardedRanker:
         return idx, val
 
     @torch.no_grad()
-    def topk(self, user_ids, input_ids, fake_ids, k: int = 10, exclude_pad: bool = True):
-        """-> (indices int64 (B,k), scores (B,k)) of this rank's users over the WHOLE catalog."""
+    def topk(self, user_ids, input_ids, fake_ids, k: int = 10, exclude_pad: bool = True, check_batch: bool = True):
+        """-> (indices int64 (B,k), scores (B,k)) of this rank's users over the WHOLE catalog.  An index is -1 (score -inf) where
+        fewer than k items are rankable.  ``check_batch`` (data parallel): verify that every rank passed the same batch size
+        (one 8-byte all-gather + host read per call; pass False in a loop whose batches are known to be equal)."""
         m = self.model
         ids = m._prep(input_ids, fake_ids, None, None, None, None)
         h_last = m._launch_fwd_last(ids[0], ids[1])[:, 0, :]          # (B, d_out)
@@ -74,6 +76,16 @@ class ShardedRanker:
             lists = [self._rank_shard(h_last, ulab, lo, hi, k, exclude_pad) for lo, hi in self.shards if hi > lo]
             return topk_merge(torch.cat([i for i, _ in lists], 1), torch.cat([v for _, v in lists], 1), k)
         # ---- one shard per rank: gather every rank's users, rank them against the own rows, exchange the lists
+        if check_batch:
+            # every rank must bring the same number of users (the gathers below are sized world x B from the LOCAL B: a ragged
+            # last evaluation batch would hang or mis-assign rows) - one tiny all-gather, then a clear error on every rank
+            nb = torch.tensor([B], device=h_last.device, dtype=torch.int64)
+            nb_all = torch.empty(self.world, device=h_last.device, dtype=torch.int64)
+            _all_gather(nb_all, nb, self.group)
+            sizes = nb_all.tolist()
+            if any(x != B for x in sizes):
+                raise ValueError(f"ShardedRanker.topk: ranks passed different batch sizes {sizes}; pad the last batch to a common size "
+                                 "(rows of padding ids rank like any other user and can be dropped afterwards)")
         h_all = torch.empty(self.world * B, h_last.shape[1], device=h_last.device, dtype=torch.float32)
         _all_gather(h_all, h_last, self.group)
         lab_all = None

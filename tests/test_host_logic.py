@@ -124,3 +124,38 @@ def test_reference_checkpoint_roundtrip(tmp_path):
     srfrd_amd.load_reference_checkpoint(m, str(path))
     for k, v in m.state_dict().items():
         assert torch.equal(v, sd[k])
+
+
+def test_gradient_views_split_the_flat_vector_in_slot_order():
+    """modules._grad_views: one split_with_sizes over [table | pad | dense ...] + a reshape per parameter (the module-level
+    backward hands autograd views of ONE flat gradient vector, which srfrd_amd.Adam then steps in place)"""
+    import torch
+    from srfrd_amd.modules import _SRFRDBase
+
+    class Fake:
+        _grad_views = _SRFRDBase._grad_views
+
+    f = Fake()
+    a, b, c = torch.zeros(3, 5), torch.zeros(4), torch.zeros(2, 2)
+    f._slots = [(a, 0), (b, 16), (c, 20)]              # 15 table floats, pad to 16, then two dense tensors; tail pad to 28
+    g = torch.arange(28, dtype=torch.float32)
+    va, vb, vc = f._grad_views(g)
+    assert va.shape == a.shape and vb.shape == b.shape and vc.shape == c.shape
+    assert torch.equal(va.reshape(-1), g[0:15]) and torch.equal(vb, g[16:20]) and torch.equal(vc.reshape(-1), g[20:24])
+    assert va.data_ptr() == g.data_ptr() and vb.data_ptr() == g.data_ptr() + 64      # views, not copies
+
+
+def test_forward_seed_is_a_host_side_function_of_the_torch_seed():
+    import torch
+    from srfrd_amd.modules import _SRFRDBase
+
+    class Fake:
+        _next_seed = _SRFRDBase._next_seed
+
+    torch.manual_seed(123)
+    f, g = Fake(), Fake()
+    s1 = [f._next_seed() for _ in range(4)]
+    s2 = [g._next_seed() for _ in range(4)]
+    assert s1 == s2 and len(set(s1)) == 4 and all(0 <= s < 2 ** 31 for s in s1)
+    torch.manual_seed(124)
+    assert [f._next_seed() for _ in range(4)] != s1
