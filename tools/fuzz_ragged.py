@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the ragged seq_len-50 kernel pair against the full-row kernels (GPU box).
+
+    python tools/fuzz_ragged.py [--cases 60] [--seed 0]
+
+Per case: a random model kind, batch size (1 .. 700: below, at and above the 512-workgroup grid, so second sequences per
+workgroup and the length-ordered selection with ties are hit), pad pattern (leading pads drawn from several distributions incl.
+all-pad and pad-free sequences, interior pads, target ids on padded positions), dropout on / off.  The SAME fused training step
+(one eager step from identical weights, deterministic scatter) runs under the default kernels and under SRFRD_NO_RAGGED=1 (the
+switch is read per launch); compared: the loss (2e-6) and every stepped parameter with the bound the suite uses for one Adam
+step from identical weights (|d| <= 2.2 lr, mean 2e-6); a batch without any target gives NaN under both, as in the reference.
+The evaluation forward (hidden state, pos / neg logits at 2e-5) is compared the same way.  Exit code 0 = every case agrees.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+I, L = 400, 50
+
+
+def make_batch(g, B, torch):
+    seq = torch.randint(1, I + 1, (B, L), generator=g)
+    pos = torch.randint(1, I + 1, (B, L), generator=g)
+    neg = torch.randint(1, I + 1, (B, L), generator=g)
+    mode = int(torch.randint(0, 4, (1,), generator=g))
+    for b in range(B):
+        if mode == 0:
+            t0 = int(torch.randint(0, L + 1, (1,), generator=g))                 # uniform, all-pad included
+        elif mode == 1:
+            t0 = int(torch.randint(0, 6, (1,), generator=g))                      # long sequences: many ties at the top
+        elif mode == 2:
+            t0 = int(torch.randint(L - 6, L + 1, (1,), generator=g))              # short ones
+        else:
+            t0 = [0, 3, 4, 5, 19, 20, 21, 35, 36, 37, 49, 50][int(torch.randint(0, 12, (1,), generator=g))]   # tile boundaries
+        seq[b, :t0] = 0
+        if int(torch.randint(0, 5, (1,), generator=g)) != 0:
+            pos[b, :t0] = 0
+            neg[b, :t0] = 0
+        if int(torch.randint(0, 6, (1,), generator=g)) == 0 and t0 + 3 < L:
+            seq[b, t0 + 1 + int(torch.randint(0, L - t0 - 2, (1,), generator=g))] = 0
+    rsq = torch.where(seq != 0, torch.randint(1, 3, (B, L), generator=g), torch.zeros_like(seq))
+    prs = torch.where(pos != 0, torch.randint(1, 3, (B, L), generator=g), torch.zeros_like(pos))
+    nrs = (neg != 0).long()
+    return seq, rsq, pos, prs, neg, nrs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    import torch
+    import srfrd_amd
+    g = torch.Generator().manual_seed(a.seed)
+    kinds = ["SASRec", "SRFR", "SRFRN", "SRFU_B"]
+    bad = 0
+    for case in range(a.cases):
+        kind = kinds[int(torch.randint(0, 4, (1,), generator=g))]
+        B = [1, 2, 7, 255, 256, 257, 511, 512, 513, 700][int(torch.randint(0, 10, (1,), generator=g))] if case % 2 == 0 \
+            else int(torch.randint(1, 701, (1,), generator=g))
+        p = [0.0, 0.5, 0.2][int(torch.randint(0, 3, (1,), generator=g))]
+        batch = make_batch(g, B, torch)
+        res = {}
+        for name, env in (("ragged", None), ("full", "SRFRD_NO_RAGGED")):
+            if env:
+                os.environ[env] = "1"
+            try:
+                torch.manual_seed(1000 + case)
+                if kind == "SASRec":
+                    m = srfrd_amd.SASRec(I, L, 50, p, 2, 1, "cuda")
+                elif kind == "SRFR":
+                    m = srfrd_amd.SRFR(I, L, 45, 5, p, 2, 1, "cuda")
+                elif kind == "SRFRN":
+                    m = srfrd_amd.SRFRN(I, L, 45, 5, p, 2, 1, "cuda")
+                else:
+                    m = srfrd_amd.SRFU_B(I, L, 50, 3, p, 2, 1, "cuda")
+                for _, q in m.named_parameters():
+                    if q.dim() >= 2:
+                        torch.nn.init.xavier_normal_(q.data)
+                m = m.cuda()
+                dev = [t.cuda() for t in batch]
+                m.eval()
+                with torch.no_grad():
+                    h, pl, nl = m(None, dev[0], dev[1], dev[2], dev[3], dev[4], dev[5])
+                m.train()
+                tr = srfrd_amd.FusedTrainer(m, B, L, seed=case, use_graph=False, deterministic=True)
+                loss = float(tr.step(None, *dev).cpu())
+                res[name] = dict(loss=loss, flat=tr.flat[:m.n_flat].cpu(), h=h.cpu(), pl=pl.cpu(), nl=nl.cpu())
+            finally:
+                if env:
+                    del os.environ[env]
+        r, f = res["ragged"], res["full"]
+        d = (r["flat"] - f["flat"]).abs()
+        errs = dict(loss=abs(r["loss"] - f["loss"]), wmax=float(d.max()), wmean=float(d.mean()),
+                    h=float((r["h"] - f["h"]).abs().max()), pl=float((r["pl"] - f["pl"]).abs().max()),
+                    nl=float((r["nl"] - f["nl"]).abs().max()))
+        ok = errs["loss"] < 2e-6 and errs["wmax"] <= 2.2e-3 and errs["wmean"] < 2e-6 and max(errs["h"], errs["pl"], errs["nl"]) < 2e-5
+        if r["loss"] != r["loss"] and f["loss"] != f["loss"]:
+            # no position with a target in the whole batch: the mean over an empty selection is NaN in the reference too
+            # (trainer.py:36-38), and so is everything the step touches - both kernels must say so
+            ok = bool((batch[2] == 0).all()) and max(errs["h"], errs["pl"], errs["nl"]) < 2e-5
+            errs["loss"] = errs["wmax"] = errs["wmean"] = 0.0
+        bad += not ok
+        print(f"case {case:3d} {kind:7s} B={B:3d} p={p:.1f} " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()) + ("" if ok else "   <-- MISMATCH"),
+              flush=True)
+    print(f"{a.cases - bad} of {a.cases} cases agree")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
