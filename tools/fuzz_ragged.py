@@ -9,7 +9,7 @@ all-pad and pad-free sequences, interior pads, target ids on padded positions), 
 (one eager step from identical weights, deterministic scatter) runs under the default kernels and under SRFRD_NO_RAGGED=1 (the
 switch is read per launch); compared: the loss (2e-6) and every stepped parameter with the bound the suite uses for one Adam
 step from identical weights (|d| <= 2.2 lr, mean 2e-6); a batch without any target gives NaN under both, as in the reference.
-The evaluation forward (hidden state, pos / neg logits at 2e-5) is compared the same way.  Exit code 0 = every case agrees.
+The evaluation forward (hidden state, pos / neg logits) and the ranking forward's top-10 scores (2e-5) are compared the same way.  Exit code 0 = every case agrees.
 """
 import argparse
 import os
@@ -85,10 +85,11 @@ def main():
                 m.eval()
                 with torch.no_grad():
                     h, pl, nl = m(None, dev[0], dev[1], dev[2], dev[3], dev[4], dev[5])
+                    tk_i, tk_v = m.topk(None, dev[0], dev[1], k=10)          # the ranking forward (last position only)
                 m.train()
                 tr = srfrd_amd.FusedTrainer(m, B, L, seed=case, use_graph=False, deterministic=True)
                 loss = float(tr.step(None, *dev).cpu())
-                res[name] = dict(loss=loss, flat=tr.flat[:m.n_flat].cpu(), h=h.cpu(), pl=pl.cpu(), nl=nl.cpu())
+                res[name] = dict(loss=loss, flat=tr.flat[:m.n_flat].cpu(), h=h.cpu(), pl=pl.cpu(), nl=nl.cpu(), tk_v=tk_v.cpu(), tk_i=tk_i.cpu())
             finally:
                 if env:
                     del os.environ[env]
@@ -96,12 +97,12 @@ def main():
         d = (r["flat"] - f["flat"]).abs()
         errs = dict(loss=abs(r["loss"] - f["loss"]), wmax=float(d.max()), wmean=float(d.mean()),
                     h=float((r["h"] - f["h"]).abs().max()), pl=float((r["pl"] - f["pl"]).abs().max()),
-                    nl=float((r["nl"] - f["nl"]).abs().max()))
-        ok = errs["loss"] < 2e-6 and errs["wmax"] <= 2.2e-3 and errs["wmean"] < 2e-6 and max(errs["h"], errs["pl"], errs["nl"]) < 2e-5
+                    nl=float((r["nl"] - f["nl"]).abs().max()), topk=float((r["tk_v"] - f["tk_v"]).abs().max()))
+        ok = errs["loss"] < 2e-6 and errs["wmax"] <= 2.2e-3 and errs["wmean"] < 2e-6 and max(errs["h"], errs["pl"], errs["nl"], errs["topk"]) < 2e-5
         if r["loss"] != r["loss"] and f["loss"] != f["loss"]:
             # no position with a target in the whole batch: the mean over an empty selection is NaN in the reference too
             # (trainer.py:36-38), and so is everything the step touches - both kernels must say so
-            ok = bool((batch[2] == 0).all()) and max(errs["h"], errs["pl"], errs["nl"]) < 2e-5
+            ok = bool((batch[2] == 0).all()) and max(errs["h"], errs["pl"], errs["nl"], errs["topk"]) < 2e-5
             errs["loss"] = errs["wmax"] = errs["wmean"] = 0.0
         bad += not ok
         print(f"case {case:3d} {kind:7s} B={B:3d} p={p:.1f} " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()) + ("" if ok else "   <-- MISMATCH"),
