@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the ragged seq_len-50 kernel pair against the full-row kernels (GPU box).
 
-    python tools/fuzz_ragged.py [--cases 60] [--seed 0]
+    python tools/fuzz_ragged.py [--cases 60] [--seed 0] [--oracle]
 
 Per case: a random model kind, batch size (1 .. 700: below, at and above the 512-workgroup grid, so second sequences per
 workgroup and the length-ordered selection with ties are hit), pad pattern (leading pads drawn from several distributions incl.
@@ -47,11 +47,53 @@ def make_batch(g, B, torch):
     return seq, rsq, pos, prs, neg, nrs
 
 
+def against_oracle(a):
+    """--oracle: the default (ragged) kernels against the CPU oracle on random SMALL batches (1 .. 12 sequences): forward,
+    every gradient through the autograd path, the ranking forward (predict) - at the suite's 1e-4.  Test infrastructure use of
+    oracle/: this is a checker, nothing here is timed or shipped."""
+    import torch
+    from oracle import srfrd_oracle as O
+    from tests.gpu_util import build_model, cuda, maxerr, random_sd
+    g = torch.Generator().manual_seed(a.seed)
+    bad = 0
+    for case in range(a.cases):
+        kind = ["SASRec", "SRFR", "SRFRN", "SRFU_B"][int(torch.randint(0, 4, (1,), generator=g))]
+        B = int(torch.randint(1, 13, (1,), generator=g))
+        cfg = O.Cfg(kind, I, L, 50) if kind == "SASRec" else (O.Cfg(kind, I, L, 45, d_fake=5) if kind in ("SRFR", "SRFRN")
+                                                                else O.Cfg(kind, I, L, 50, n_labels=3))
+        sd = random_sd(cfg, 100 + case)
+        model = build_model(cfg, sd).train()
+        batch = make_batch(g, B, torch)
+        if bool((batch[2] == 0).all()):
+            batch[2][0, L - 1] = 1 + case % I          # (the loss of a batch without targets is NaN: nothing to compare)
+            batch[4][0, L - 1] = 1 + (case * 7) % I
+        loss_o, grads_o, h_o, pl_o, nl_o = O.grads_of(cfg, sd, batch)
+        seq, rsq, pos, prs, neg, nrs = cuda(*batch)
+        h, pl, nl = model(None, seq, rsq, pos, prs, neg, nrs)
+        idx = torch.where(pos != 0)
+        crit = torch.nn.BCEWithLogitsLoss()
+        loss = crit(pl[idx], torch.ones_like(pl)[idx]) + crit(nl[idx], torch.zeros_like(nl)[idx])
+        loss.backward()
+        cand = torch.arange(1, 102).repeat(B, 1)
+        errs = dict(h=maxerr(h, h_o), pl=maxerr(pl, pl_o), nl=maxerr(nl, nl_o), loss=abs(float(loss.detach()) - float(loss_o)),
+                    grad=max(maxerr(p.grad, grads_o[k]) for k, p in model.named_parameters()),
+                    predict=maxerr(model.predict(None, seq, rsq, cand.cuda()), O.predict(cfg, sd, batch[0], batch[1], cand)))
+        ok = max(errs.values()) < 1e-4
+        bad += not ok
+        print(f"case {case:3d} {kind:7s} B={B:2d} " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()) + ("" if ok else "   <-- MISMATCH"),
+              flush=True)
+    print(f"{a.cases - bad} of {a.cases} oracle cases agree")
+    sys.exit(1 if bad else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--oracle", action="store_true", help="small random batches against the CPU oracle instead of the full-row kernels")
     a = ap.parse_args()
+    if a.oracle:
+        return against_oracle(a)
     import torch
     import srfrd_amd
     g = torch.Generator().manual_seed(a.seed)
