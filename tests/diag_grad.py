@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: the fused step's GRADIENT (before Adam) against the oracle's, element by element, for one geometry.
 
-    python tools/diag_grad.py --kind SASRec --L 144 --B 300 [--dropout 0.5] [--items 400]
+    python tests/diag_grad.py --kind SASRec --L 144 --B 300 [--dropout 0.5] [--items 400]
 
 Prints the largest absolute differences with parameter name / index and, for item-table rows, how often the row is touched."""
 import argparse

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the ragged seq_len-50 kernel pair against the full-row kernels (GPU box).
 
-    python tools/fuzz_ragged.py [--cases 60] [--seed 0] [--oracle]
+    python tests/fuzz_ragged.py [--cases 60] [--seed 0] [--oracle]
 
 Per case: a random model kind, batch size (1 .. 700: below, at and above the 512-workgroup grid, so second sequences per
 workgroup and the length-ordered selection with ties are hit), pad pattern (leading pads drawn from several distributions incl.
@@ -48,15 +48,21 @@ def make_batch(g, B, torch):
 
 
 def against_oracle(a):
+    bad = run_vs_oracle(a.cases, a.seed)
+    print(f"{a.cases - bad} of {a.cases} oracle cases agree")
+    sys.exit(1 if bad else 0)
+
+
+def run_vs_oracle(cases, seed, verbose=True):
     """--oracle: the default (ragged) kernels against the CPU oracle on random SMALL batches (1 .. 12 sequences): forward,
     every gradient through the autograd path, the ranking forward (predict) - at the suite's 1e-4.  Test infrastructure use of
     oracle/: this is a checker, nothing here is timed or shipped."""
     import torch
     from oracle import srfrd_oracle as O
     from tests.gpu_util import build_model, cuda, maxerr, random_sd
-    g = torch.Generator().manual_seed(a.seed)
+    g = torch.Generator().manual_seed(seed)
     bad = 0
-    for case in range(a.cases):
+    for case in range(cases):
         kind = ["SASRec", "SRFR", "SRFRN", "SRFU_B"][int(torch.randint(0, 4, (1,), generator=g))]
         B = int(torch.randint(1, 13, (1,), generator=g))
         cfg = O.Cfg(kind, I, L, 50) if kind == "SASRec" else (O.Cfg(kind, I, L, 45, d_fake=5) if kind in ("SRFR", "SRFRN")
@@ -80,10 +86,10 @@ def against_oracle(a):
                     predict=maxerr(model.predict(None, seq, rsq, cand.cuda()), O.predict(cfg, sd, batch[0], batch[1], cand)))
         ok = max(errs.values()) < 1e-4
         bad += not ok
-        print(f"case {case:3d} {kind:7s} B={B:2d} " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()) + ("" if ok else "   <-- MISMATCH"),
-              flush=True)
-    print(f"{a.cases - bad} of {a.cases} oracle cases agree")
-    sys.exit(1 if bad else 0)
+        if verbose or not ok:
+            print(f"case {case:3d} {kind:7s} B={B:2d} " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()) + ("" if ok else "   <-- MISMATCH"),
+                  flush=True)
+    return bad
 
 
 def main():
@@ -94,12 +100,18 @@ def main():
     a = ap.parse_args()
     if a.oracle:
         return against_oracle(a)
+    bad = run_vs_full(a.cases, a.seed)
+    print(f"{a.cases - bad} of {a.cases} cases agree")
+    sys.exit(1 if bad else 0)
+
+
+def run_vs_full(cases, seed, verbose=True):
     import torch
     import srfrd_amd
-    g = torch.Generator().manual_seed(a.seed)
+    g = torch.Generator().manual_seed(seed)
     kinds = ["SASRec", "SRFR", "SRFRN", "SRFU_B"]
     bad = 0
-    for case in range(a.cases):
+    for case in range(cases):
         kind = kinds[int(torch.randint(0, 4, (1,), generator=g))]
         B = [1, 2, 7, 255, 256, 257, 511, 512, 513, 700][int(torch.randint(0, 10, (1,), generator=g))] if case % 2 == 0 \
             else int(torch.randint(1, 701, (1,), generator=g))
@@ -147,10 +159,10 @@ def main():
             ok = bool((batch[2] == 0).all()) and max(errs["h"], errs["pl"], errs["nl"], errs["topk"]) < 2e-5
             errs["loss"] = errs["wmax"] = errs["wmean"] = 0.0
         bad += not ok
-        print(f"case {case:3d} {kind:7s} B={B:3d} p={p:.1f} " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()) + ("" if ok else "   <-- MISMATCH"),
-              flush=True)
-    print(f"{a.cases - bad} of {a.cases} cases agree")
-    sys.exit(1 if bad else 0)
+        if verbose or not ok:
+            print(f"case {case:3d} {kind:7s} B={B:3d} p={p:.1f} " + " ".join(f"{k}={v:.1e}" for k, v in errs.items()) + ("" if ok else "   <-- MISMATCH"),
+                  flush=True)
+    return bad
 
 
 if __name__ == "__main__":

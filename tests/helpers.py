@@ -84,7 +84,7 @@ def assert_post_adam(msd, sd, grad_hists, D, lr=1e-3, noise=5e-6, outliers=0.0):
     2 * steps * lr: opposite Adam steps).  For tests with millions of ReLU units per step only: fp32 training through ReLU is discontinuous - a
     unit whose pre-activation is within rounding of zero takes derivative 1 in one implementation and 0 in the other, and
     the gradient of THAT token (its item rows, a few per cent of them) differs while every forward output agrees to 1e-7.
-    At 300 x 144 x 50 x 2 units about one such unit per step is expected (tools/diag_grad.py shows it: identical "error"
+    At 300 x 144 x 50 x 2 units about one such unit per step is expected (tests/diag_grad.py shows it: identical "error"
     from two independent backward kernels, gone with another batch seed).  A wrong kernel moves whole tensors, not a
     handful of elements of one item row."""
     tight = total = 0
