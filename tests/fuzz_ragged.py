@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 I, L = 400, 50
 
 
-def make_batch(g, B, torch):
+def make_batch(g, B, torch, L=L):
     seq = torch.randint(1, I + 1, (B, L), generator=g)
     pos = torch.randint(1, I + 1, (B, L), generator=g)
     neg = torch.randint(1, I + 1, (B, L), generator=g)
@@ -34,7 +34,7 @@ def make_batch(g, B, torch):
         elif mode == 2:
             t0 = int(torch.randint(L - 6, L + 1, (1,), generator=g))              # short ones
         else:
-            t0 = [0, 3, 4, 5, 19, 20, 21, 35, 36, 37, 49, 50][int(torch.randint(0, 12, (1,), generator=g))]   # tile boundaries
+            t0 = min(L, [0, 3, 4, 5, 19, 20, 21, 35, 36, 37, 49, 50][int(torch.randint(0, 12, (1,), generator=g))] * L // 50)   # tile boundaries (seq_len 50)
         seq[b, :t0] = 0
         if int(torch.randint(0, 5, (1,), generator=g)) != 0:
             pos[b, :t0] = 0
@@ -48,12 +48,12 @@ def make_batch(g, B, torch):
 
 
 def against_oracle(a):
-    bad = run_vs_oracle(a.cases, a.seed)
+    bad = run_vs_oracle(a.cases, a.seed, L=a.seq_len, max_b=12 if a.seq_len <= 64 else 5)
     print(f"{a.cases - bad} of {a.cases} oracle cases agree")
     sys.exit(1 if bad else 0)
 
 
-def run_vs_oracle(cases, seed, verbose=True):
+def run_vs_oracle(cases, seed, verbose=True, L=L, max_b=12):
     """--oracle: the default (ragged) kernels against the CPU oracle on random SMALL batches (1 .. 12 sequences): forward,
     every gradient through the autograd path, the ranking forward (predict) - at the suite's 1e-4.  Test infrastructure use of
     oracle/: this is a checker, nothing here is timed or shipped."""
@@ -64,12 +64,12 @@ def run_vs_oracle(cases, seed, verbose=True):
     bad = 0
     for case in range(cases):
         kind = ["SASRec", "SRFR", "SRFRN", "SRFU_B"][int(torch.randint(0, 4, (1,), generator=g))]
-        B = int(torch.randint(1, 13, (1,), generator=g))
+        B = int(torch.randint(1, max_b + 1, (1,), generator=g))
         cfg = O.Cfg(kind, I, L, 50) if kind == "SASRec" else (O.Cfg(kind, I, L, 45, d_fake=5) if kind in ("SRFR", "SRFRN")
                                                                 else O.Cfg(kind, I, L, 50, n_labels=3))
         sd = random_sd(cfg, 100 + case)
         model = build_model(cfg, sd).train()
-        batch = make_batch(g, B, torch)
+        batch = make_batch(g, B, torch, L)
         if bool((batch[2] == 0).all()):
             batch[2][0, L - 1] = 1 + case % I          # (the loss of a batch without targets is NaN: nothing to compare)
             batch[4][0, L - 1] = 1 + (case * 7) % I
@@ -96,6 +96,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--seq-len", type=int, default=L, help="--oracle only: other lengths run the long-sequence kernels (100: slots, 101 .. 208: row-chunked)")
     ap.add_argument("--oracle", action="store_true", help="small random batches against the CPU oracle instead of the full-row kernels")
     a = ap.parse_args()
     if a.oracle:
