@@ -192,6 +192,36 @@ class _SRFRDBase(nn.Module):
         self._ensure_flat()
         return self._flat
 
+    def _current_slots(self, table):
+        """[(parameter, flat offset)] of the parameters the module tree holds NOW.  forward() asks on every call (a parameter or
+        a submodule may have been replaced since the last one); walking the tree through nn.Module.__getattr__ costs ~60 us of
+        host time per call (62 attribute lookups), so the (module path, name) of every slot is resolved once and each call
+        follows the paths through the _modules / _parameters dictionaries - the objects found are always the current ones."""
+        paths = getattr(self, "_slot_paths", None)
+        if paths is not None:
+            try:
+                out = []
+                for path, pname, off in paths:
+                    m = self
+                    for n in path:
+                        m = m._modules[n]
+                    out.append((m._parameters[pname], off))
+                if out[0][0] is table:
+                    return out
+            except (KeyError, AttributeError):
+                pass
+        slots = [(table, 0)] + [(p, self.n_table_pad + off) for p, off in self._dense_params()]
+        where = {}
+        for mname, mod in self.named_modules():
+            for pname, q in mod._parameters.items():
+                if q is not None:
+                    where.setdefault(id(q), (tuple(mname.split(".")) if mname else (), pname))
+        try:
+            self._slot_paths = [where[id(q)] + (off,) for q, off in slots]
+        except KeyError:
+            self._slot_paths = None
+        return slots
+
     def _ensure_flat(self):
         lay = self.layout
         table = self._item_param()
@@ -201,7 +231,7 @@ class _SRFRDBase(nn.Module):
                                ".to('cuda'). There is no CPU fallback.")
         if lay.D > _lib.MAX_D:
             raise NotImplementedError(f"the fused MI355X kernels cover hidden width <= 64 (got width {lay.D})")
-        slots = [(table, 0)] + [(p, self.n_table_pad + off) for p, off in self._dense_params()]
+        slots = self._current_slots(table)
         flat = self._flat
         if flat is not None and flat.device == dev:
             base = flat.data_ptr()

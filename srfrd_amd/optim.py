@@ -58,10 +58,10 @@ class Adam(torch.optim.Optimizer):
 
     def _flat_grad(self):
         """the gradients as one vector aligned with the flat parameters: in place when they already are views of one"""
-        base = None
+        base = last = None
         for p, off, n in self._spans:
             g = p.grad
-            if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
+            if g is None or not g.is_contiguous():
                 base = None
                 break
             b = g.data_ptr() - 4 * off
@@ -71,7 +71,8 @@ class Adam(torch.optim.Optimizer):
                 base = None
                 break
             last = g
-        if base is not None:
+        if base is not None and last.dtype == torch.float32 and last.device == self._flat.device:
+            # (one dtype / device test: tensors laid out at the parameters' own offsets of one buffer are views of one vector)
             st = last.untyped_storage()
             if st.data_ptr() <= base and base + 4 * self._flat.numel() <= st.data_ptr() + st.nbytes():
                 return C.c_void_p(base), last          # (keep a reference alive until the launch is enqueued)

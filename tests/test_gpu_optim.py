@@ -83,3 +83,38 @@ def test_flat_adam_takes_gradients_that_are_not_views_of_one_vector():
             (pl.sum() * 1e-3 - nl.sum() * 1e-3).backward()
         o.step()
     _close(m1.state_dict(), m2.state_dict())
+
+
+def test_replaced_parameters_and_submodules_are_picked_up_by_the_next_forward():
+    """forward() resolves its parameter slots through cached module paths (srfrd_amd/modules.py:_current_slots): a parameter
+    object or a whole submodule replaced between two calls must be what the next call computes with - checked against a fresh
+    model loaded from the modified model's state_dict (bit-equal outputs), and training must go on from there."""
+    import srfrd_amd
+    m = _model().eval()
+    batch = srfrd_amd.synthetic_batch(400, 50, 32, seed=5, device="cuda")
+    u, seq, rsq, pos, prs, neg, nrs = batch
+    with torch.no_grad():
+        h0 = m(u, seq, rsq, pos, prs, neg, nrs)[0].clone()
+        # (a) a new Parameter object in place of an old one
+        m.last_layernorm.weight = torch.nn.Parameter(torch.full((50,), 1.5, device="cuda"))
+        # (b) a whole submodule replaced
+        ln = torch.nn.LayerNorm(50, eps=1e-8).cuda()
+        ln.weight.data.uniform_(0.5, 1.5)
+        m.attention_layernorms[1] = ln
+        # (c) in-place edits of an existing parameter
+        m.pos_emb.weight.data.mul_(0.5)
+        h1 = m(u, seq, rsq, pos, prs, neg, nrs)[0].clone()
+    assert float((h1 - h0).abs().max()) > 1e-3
+    ref = _model().eval()
+    ref.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        h2 = ref(u, seq, rsq, pos, prs, neg, nrs)[0]
+    assert torch.equal(h1, h2)
+    # every parameter is a view of the (re-built) flat vector again, and the optimizer steps the new objects
+    m.train()
+    opt = srfrd_amd.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.98))
+    before = m.last_layernorm.weight.detach().clone()
+    _step(m, opt, batch)
+    assert float((m.last_layernorm.weight.detach() - before).abs().max()) > 0
+    base = m.flat_parameters().data_ptr()
+    assert all(base <= p.data_ptr() < base + 4 * m.flat_parameters().numel() for p in m.parameters())
